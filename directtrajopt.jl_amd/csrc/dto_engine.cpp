@@ -1,0 +1,997 @@
+// dto_engine.cpp -- host side of the C ABI declared in include/dto_engine.h.
+//
+// Owns the handle, builds the sparsity structure in the reference's exact order
+// (src/solvers/evaluator.jl:119-209, closed forms of SURVEY.md §3.6 + a per-column prefix sum for
+// the value-dependent constraint entries), and orchestrates the HIP kernels of dto_kernels.hip.
+// There is NO CPU fallback: every evaluation runs on the GPU or fails with an error code.
+#include "../../include/dto_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "dto_kernels.h"
+
+using namespace dto;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError {
+    std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            char buf_[512];                                                                      \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                        \
+            throw HipError{buf_};                                                                \
+        }                                                                                        \
+    } while (0)
+
+template <class T>
+T* dalloc(size_t n) {
+    void* p = nullptr;
+    if (n == 0) n = 1;
+    HIP_CHECK(hipMalloc(&p, n * sizeof(T)));
+    return static_cast<T*>(p);
+}
+template <class T>
+T* dupload(const std::vector<T>& v) {
+    T* p = dalloc<T>(v.size());
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+
+struct BilHost {
+    KBil k;
+    SweepBuf fw{}, ad{};
+    int T_alloc = 0;
+    std::vector<double> g1;   // ||G_j||_1
+    std::vector<double> n2;   // ||G_i G_j||_1, (m+1)^2
+    double* d_g1 = nullptr;
+    double* d_n2 = nullptr;
+    ChainWork chain{};
+    int chain_cap = 0;
+};
+
+struct ConHost {
+    KCon k{};
+    int equality = 0;
+    int64_t n_times_total = 0;
+    int64_t row_off = 0;  // global 0-based first row
+    std::vector<int64_t> times0;  // all times (0-based knots), reference order
+    std::vector<int32_t> comps;
+};
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int cat;
+    double flops;
+};
+
+}  // namespace
+
+struct dto_handle {
+    std::string err;
+    int device = 0;
+    int64_t N = 0, K = 0;
+    int z = 0, gd = 0, dt_idx = 0, D = 0;
+    int eval_hessian = 1;
+    int64_t n_vars = 0, n_cons = 0, n_dyn = 0, jac_nnz = 0, hess_nnz = 0;
+    int64_t k_lo = 1, k_hi = 1;
+    KProb P{};
+    std::vector<int64_t> colptr;            // host copy
+    std::vector<int64_t> con_cols, con_rows;  // constraint pattern entries sorted by (col,row), 0-based
+    std::vector<int64_t> con_colstart;      // index into con_* of each column with entries (map col -> range)
+    std::vector<BilHost> bil;
+    std::vector<KDer> der;
+    std::vector<int> integ_kind, integ_index;  // reference order -> (kind, index into bil/der)
+    std::vector<int> integ_dim;
+    std::vector<int64_t> integ_row_off;
+    std::vector<ConHost> con;
+    std::vector<KObj> obj;
+    std::vector<std::pair<int64_t, int64_t>> row_segments;  // (global start 0-based, len)
+    int64_t cons_len = 0;
+    dto_shard_info info{};
+
+    // device scratch
+    int64_t* d_colptr = nullptr;
+    double* d_Z = nullptr;
+    double* d_mu = nullptr;
+    double* d_out = nullptr;  // host-API staging for the largest output
+    size_t d_out_cap = 0;
+    double* d_partial = nullptr;
+    double* d_f = nullptr;
+    double* d_bounds = nullptr;  // [2] max beta, max b1 (as uint64 bit patterns)
+    double* h_pinned = nullptr;  // [4]
+    hipStream_t stream = nullptr;
+
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    int last_smax = 0, last_terms = 0;
+    std::vector<void*> owned;  // device allocations to free
+
+    ~dto_handle();
+};
+
+dto_handle::~dto_handle() {
+    (void)hipSetDevice(device);
+    for (auto& r : prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (void* p : owned) (void)hipFree(p);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+namespace {
+
+template <class T>
+T* own(dto_handle* h, T* p) {
+    h->owned.push_back(p);
+    return p;
+}
+
+int fail(dto_handle* h, const std::string& m) {
+    if (h) h->err = m; else g_create_error = m;
+    return 1;
+}
+
+inline int pad64(int n) { return ((n + 63) / 64) * 64; }
+
+struct ProfScope {
+    dto_handle* h;
+    hipStream_t st;
+    bool on;
+    ProfRec r{};
+    ProfScope(dto_handle* h_, hipStream_t st_, int cat, double flops) : h(h_), st(st_), on(h_->profiling) {
+        if (!on) return;
+        r.cat = cat;
+        r.flops = flops;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        h->prof.push_back(r);
+    }
+};
+enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2 };
+
+// ------------------------------------------------------------------------------------------
+// structure
+// ------------------------------------------------------------------------------------------
+
+// number of integrator rows touching a column of knot kn (0-based): D per adjacent interval
+inline int col_cnt(const dto_handle* h, int64_t kn) { return (kn >= 1 ? 1 : 0) + (kn < h->K ? 1 : 0); }
+
+double con_jac_value(const ConHost& c, const double* zk, int comp_i) {
+    double s = 0.0;
+    for (int q : c.comps) s += zk[q] * zk[q];
+    const double v = zk[c.comps[comp_i]];
+    return c.k.kind == DTO_CONSTRAINT_NORM_MINUS_C ? v / std::sqrt(s) : 2.0 * v;
+}
+
+void build_structure(dto_handle* h, const double* Z0) {
+    const int64_t nv = h->n_vars;
+    // constraint pattern = numeric Jacobian at Z0, exact zeros not stored (evaluator.jl:136)
+    std::vector<std::pair<int64_t, int64_t>> ent;
+    for (auto& c : h->con) {
+        for (int64_t i = 0; i < c.n_times_total; ++i) {
+            const int64_t kn = c.times0[i];
+            const double* zk = Z0 + kn * h->z;
+            for (size_t q = 0; q < c.comps.size(); ++q) {
+                const double v = con_jac_value(c, zk, (int)q);
+                if (v != 0.0) ent.emplace_back(kn * h->z + c.comps[q], c.row_off + i);
+            }
+        }
+    }
+    std::sort(ent.begin(), ent.end());
+    ent.erase(std::unique(ent.begin(), ent.end()), ent.end());
+    h->con_cols.resize(ent.size());
+    h->con_rows.resize(ent.size());
+    std::vector<int32_t> extra(nv, 0);
+    for (size_t i = 0; i < ent.size(); ++i) {
+        h->con_cols[i] = ent[i].first;
+        h->con_rows[i] = ent[i].second;
+        extra[ent[i].first]++;
+    }
+    h->colptr.assign(nv + 1, 0);
+    for (int64_t kn = 0; kn < h->N; ++kn) {
+        const int64_t per = (int64_t)h->D * col_cnt(h, kn);
+        for (int j = 0; j < h->z; ++j) {
+            const int64_t c = kn * h->z + j;
+            h->colptr[c + 1] = h->colptr[c] + per + extra[c];
+        }
+    }
+    for (int64_t c = h->N * h->z; c < nv; ++c) h->colptr[c + 1] = h->colptr[c];  // global columns: no entries
+    h->jac_nnz = h->colptr[nv];
+    const int64_t z = h->z;
+    h->hess_nnz = h->N * (z * (z + 1) / 2) + h->K * z * z;  // evaluator.jl:201-202 on the block pattern
+}
+
+// first constraint-pattern entry of column c
+inline size_t con_lower(const dto_handle* h, int64_t c) {
+    return std::lower_bound(h->con_cols.begin(), h->con_cols.end(), c) - h->con_cols.begin();
+}
+
+int64_t hess_block_start(const dto_handle* h, int64_t kn) {
+    const int64_t z = h->z, tri = z * (z + 1) / 2;
+    return kn == 0 ? 0 : tri + (kn - 1) * (z * z + tri);
+}
+
+// ------------------------------------------------------------------------------------------
+// sweeps and chain
+// ------------------------------------------------------------------------------------------
+
+void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool adjoint) {
+    const int npad = b.k.npad;
+    w.npad = npad;
+    w.TN = (npad % 128 == 0) ? 128 : 64;
+    int64_t nint = std::max<int64_t>(h->P.n_int, 1);
+    w.Kpad = (int)(((nint + w.TN - 1) / w.TN) * w.TN);
+    const size_t typesz = (size_t)w.Kpad * npad;
+    w.Z[0] = own(h, dalloc<double>(typesz * T));
+    w.Z[1] = own(h, dalloc<double>(typesz * T));
+    w.S = own(h, dalloc<double>(typesz * T));
+    w.GY = own(h, dalloc<double>(typesz));
+    w.W = adjoint ? own(h, dalloc<double>(typesz * (b.k.m + 1))) : nullptr;
+    w.scaleA = own(h, dalloc<double>((size_t)(b.k.m + 1) * w.Kpad));
+    w.scaleU = own(h, dalloc<double>((size_t)(b.k.m + 1) * w.Kpad));
+    w.scaleE = own(h, dalloc<double>(w.Kpad));
+    w.termnorm = own(h, dalloc<unsigned long long>((size_t)3 * T * w.Kpad));
+    w.sumnorm = own(h, dalloc<unsigned long long>((size_t)T * w.Kpad));
+    w.active = own(h, dalloc<int32_t>(w.Kpad / w.TN));
+    w.stats = own(h, dalloc<int32_t>(4));
+    HIP_CHECK(hipMemset(w.stats, 0, 4 * sizeof(int32_t)));
+    // padding columns/rows must be finite zeros from the start
+    HIP_CHECK(hipMemset(w.Z[0], 0, typesz * T * sizeof(double)));
+    HIP_CHECK(hipMemset(w.Z[1], 0, typesz * T * sizeof(double)));
+    HIP_CHECK(hipMemset(w.S, 0, typesz * T * sizeof(double)));
+    HIP_CHECK(hipMemset(w.GY, 0, typesz * sizeof(double)));
+}
+
+SweepTypes make_types(int m, bool second_order) {
+    SweepTypes ty{};
+    int T = 0;
+    ty.t[T++] = TypeDesc{0, {0, 0}, {0, 0}, {0, 0}};  // p
+    for (int j = 0; j < m; ++j) {                    // d^j: + E_j p
+        TypeDesc d{};
+        d.n_extra = 1; d.gen[0] = 1 + j; d.src[0] = 0; d.mult[0] = 1.0;
+        ty.t[T++] = d;
+    }
+    if (second_order) {
+        for (int i = 0; i < m; ++i)
+            for (int j = i; j < m; ++j) {  // h^{ij}: + E_i d^j + E_j d^i
+                TypeDesc d{};
+                if (i == j) {
+                    d.n_extra = 1; d.gen[0] = 1 + i; d.src[0] = 1 + i; d.mult[0] = 2.0;
+                } else {
+                    d.n_extra = 2;
+                    d.gen[0] = 1 + i; d.src[0] = 1 + j; d.mult[0] = 1.0;
+                    d.gen[1] = 1 + j; d.src[1] = 1 + i; d.mult[1] = 1.0;
+                }
+                ty.t[T++] = d;
+            }
+    }
+    ty.T = T;
+    return ty;
+}
+
+struct Bounds {
+    double beta, b1;
+};
+
+Bounds get_bounds(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(h->d_bounds, 0, 2 * sizeof(double), st));
+    launch_norm_bounds(st, h->P, b.k, dZ, b.d_g1, b.d_n2, reinterpret_cast<unsigned long long*>(h->d_bounds));
+    HIP_CHECK(hipMemcpyAsync(h->h_pinned, h->d_bounds, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    Bounds r{h->h_pinned[0], h->h_pinned[1]};
+    return r;
+}
+
+struct SweepPlan {
+    int q, d_ub;
+};
+
+SweepPlan plan_sweep(double beta) {
+    SweepPlan p{1, 12};
+    if (!(beta == beta) || beta > 1e6) {  // non-finite iterate: bounded work, NaN/Inf propagates to the output
+        p.q = 1; p.d_ub = 30;
+        return p;
+    }
+    const double theta_v = 7.0;  // cancellation budget e^7 ~ 1e3 (3 digits) on the Taylor sums
+    p.q = std::max(1, (int)std::ceil(beta / theta_v));
+    const double br = beta / p.q;
+    int t = 8;
+    double term = 1.0;
+    for (int i = 1; i <= t; ++i) term *= br / i;
+    while (term > 1e-19 && t < 200) { ++t; term *= br / t; }
+    p.d_ub = t + 6;
+    return p;
+}
+
+void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
+               int src_kind, int transposed, const SweepPlan& plan, hipStream_t st) {
+    const double flops_step = [&] {
+        double segs = 0;
+        for (int t = 0; t < ty.T; ++t) {
+            segs += b.k.m + 1;
+            for (int e = 0; e < ty.t[t].n_extra; ++e) segs += ty.t[t].mult[e];
+        }
+        return 2.0 * b.k.npad * (double)b.k.npad * w.Kpad * segs;
+    }();
+    launch_sweep_init(st, h->P, b.k, w, ty, dZ, dmu, src_kind, plan.q);
+    for (int round = 0; round < plan.q; ++round) {
+        if (round > 0) launch_sweep_restart(st, w, ty.T);
+        int buf = 0;
+        for (int t = 0; t < plan.d_ub; ++t) {
+            {
+                ProfScope ps(h, st, CAT_SWEEP, flops_step);
+                launch_sweep_step(st, b.k, w, ty, transposed, t, buf);
+            }
+            launch_sweep_check(st, w, ty.T, t, 1.1e-16);
+            buf ^= 1;
+        }
+    }
+}
+
+void alloc_chain(dto_handle* h, BilHost& b, int cap) {
+    const size_t nn = (size_t)b.k.npad * b.k.npad;
+    for (int i = 0; i < 6; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
+    b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
+    b.chain.coef = own(h, dalloc<double>((size_t)cap * COEF_STRIDE));
+    b.chain.s = own(h, dalloc<int32_t>(cap));
+    b.chain.smax = own(h, dalloc<int32_t>(1));
+    HIP_CHECK(hipMemset(b.chain.smax, 0, sizeof(int32_t)));
+    b.chain_cap = cap;
+}
+
+int chunk_size(const dto_handle* h, int npad) {
+    // workspace budget for the 6 chain matrices; DTO_CHAIN_CHUNK overrides
+    if (const char* e = getenv("DTO_CHAIN_CHUNK")) {
+        int v = atoi(e);
+        if (v > 0) return v;
+    }
+    const double budget = 24e9;
+    int c = (int)(budget / (6.0 * npad * (double)npad * 8.0));
+    c = std::max(8, (c / 8) * 8);
+    return (int)std::min<int64_t>(c, std::max<int64_t>(h->P.n_int, 1));
+}
+
+// exp(dt G(u_k)) for every owned interval; -E_k goes straight into the Jacobian slab.
+void run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st) {
+    const int npad = b.k.npad;
+    const int64_t nint = h->P.n_int;
+    if (nint <= 0) return;
+    const int cap = b.chain_cap;
+    int s_ub = 1;
+    if (b1max == b1max && b1max > THETA_16) s_ub = std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
+    s_ub = std::min(s_ub, 60);
+    const double gemm_flops = 2.0 * npad * (double)npad * npad;
+    HIP_CHECK(hipMemsetAsync(b.chain.smax, 0, sizeof(int32_t), st));
+    for (int64_t c0 = 0; c0 < nint; c0 += cap) {
+        const int nb = (int)std::min<int64_t>(cap, nint - c0);
+        const int64_t int0 = h->P.kn_lo + c0;
+        ChainWork& w = b.chain;
+        launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
+        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
+        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
+        launch_norm1(st, npad, nb, w);
+        launch_expm_params(st, nb, s_ub, w);
+        launch_poly_h3(st, npad, nb, w);
+        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 8); }
+        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
+        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
+        int src = 4;
+        for (int it = 0; it < s_ub; ++it) {
+            ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb);
+            launch_bgemm_square(st, npad, nb, w, src, src == 4 ? 5 : 4, it, h->P, b.k, int0, vals);
+            src = src == 4 ? 5 : 4;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// callbacks (device-pointer forms)
+// ------------------------------------------------------------------------------------------
+
+void do_objective(dto_handle* h, const double* dZ, double* df, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(df, 0, sizeof(double), st));
+    for (auto& o : h->obj) launch_objective(st, h->P, o, dZ, h->d_partial, df);
+}
+
+void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(dgrad, 0, sizeof(double) * (size_t)h->info.grad_len, st));
+    for (auto& o : h->obj) launch_gradient(st, h->P, o, dZ, dgrad);
+}
+
+void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
+    for (auto& b : h->bil) {
+        if (h->P.n_int > 0) {
+            Bounds bd = get_bounds(h, b, dZ, st);
+            SweepPlan plan = plan_sweep(bd.beta);
+            SweepTypes ty = make_types(0, false);
+            run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
+            launch_cons_bilinear(st, h->P, b.k, b.fw, dZ, dg);
+        }
+    }
+    for (auto& d : h->der) launch_cons_derivative(st, h->P, d, dZ, dg);
+    for (auto& c : h->con) launch_cons_knot(st, h->P, c.k, dZ, dg);
+}
+
+void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));  // fill!(∂, 0), evaluator.jl:497
+    h->last_terms = 0;
+    for (auto& b : h->bil) {
+        Bounds bd{0, 0};
+        if (h->P.n_int > 0) {
+            bd = get_bounds(h, b, dZ, st);
+            run_chain(h, b, dZ, dvals, bd.b1, st);
+            SweepPlan plan = plan_sweep(bd.beta);
+            SweepTypes ty = make_types(b.k.m, false);
+            run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
+            launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+        }
+        launch_jac_bilinear(st, h->P, b.k, b.fw, dvals);
+    }
+    for (auto& d : h->der) launch_jac_derivative(st, h->P, d, dZ, dvals);
+    for (auto& c : h->con) launch_jac_knot(st, h->P, c.k, dZ, dvals);
+}
+
+void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dH, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, st));  // fill!(H, 0), evaluator.jl:571
+    // integrators in reference order (evaluator.jl:574-598)
+    for (size_t i = 0; i < h->integ_kind.size(); ++i) {
+        if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) {
+            BilHost& b = h->bil[h->integ_index[i]];
+            if (h->P.n_int <= 0) continue;
+            Bounds bd = get_bounds(h, b, dZ, st);
+            SweepPlan plan = plan_sweep(bd.beta);
+            SweepTypes ty2 = make_types(b.k.m, true);
+            run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st);
+            launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+            // W_j = G_j' mu from the adjoint sweep's term-0 buffer, then the adjoint sweep itself
+            launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
+            launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
+            SweepTypes ty1 = make_types(b.k.m, false);
+            run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st);
+            launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
+            launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH);
+        } else {
+            launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
+        }
+    }
+    for (auto& c : h->con) launch_hess_knot(st, h->P, c.k, dZ, dmu, dH);
+    if (sigma != 0.0)
+        for (auto& o : h->obj) launch_hess_objective(st, h->P, o, dZ, sigma, dH);
+}
+
+double* staging(dto_handle* h, size_t n) {
+    if (n > h->d_out_cap) {
+        h->d_out = own(h, dalloc<double>(n));
+        h->d_out_cap = n;
+    }
+    return h->d_out;
+}
+
+template <class F>
+int guarded(dto_handle* h, F&& f) {
+    if (!h) return fail(nullptr, "null handle");
+    try {
+        HIP_CHECK(hipSetDevice(h->device));
+        f();
+        return 0;
+    } catch (const HipError& e) {
+        return fail(h, e.msg);
+    } catch (const std::exception& e) {
+        return fail(h, e.what());
+    }
+}
+
+void upload_Z(dto_handle* h, const double* Z) {
+    HIP_CHECK(hipMemcpyAsync(h->d_Z, Z, sizeof(double) * (size_t)h->n_vars, hipMemcpyHostToDevice, h->stream));
+}
+
+void check_sweeps(dto_handle* h) {
+    // after a synchronised call: the Taylor recurrences must have terminated inside their step budget
+    for (auto& b : h->bil) {
+        for (SweepBuf* w : {&b.fw, &b.ad}) {
+            if (!w->stats) continue;
+            int32_t st[2];
+            HIP_CHECK(hipMemcpy(st, w->stats, sizeof(st), hipMemcpyDeviceToHost));
+            h->last_terms = std::max(h->last_terms, st[1]);
+            if (st[0] != 0) throw HipError{"generator sweep did not converge within its step budget"};
+        }
+    }
+    h->last_smax = 0;
+    for (auto& b : h->bil) {
+        int32_t s = 0;
+        HIP_CHECK(hipMemcpy(&s, b.chain.smax, sizeof(s), hipMemcpyDeviceToHost));
+        h->last_smax = std::max(h->last_smax, (int)s);
+    }
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+
+extern "C" {
+
+const char* dto_last_error(const dto_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void dto_destroy(dto_handle* h) { delete h; }
+
+int dto_create(const dto_problem_desc* d, dto_handle** out) {
+    if (!d || !out) return fail(nullptr, "dto_create: null argument");
+    *out = nullptr;
+    if (d->abi_version != DTO_ABI_VERSION) return fail(nullptr, "dto_create: ABI version mismatch");
+    if (d->N < 2) return fail(nullptr, "dto_create: need at least 2 knots");
+    if (d->z < 1 || d->gd < 0) return fail(nullptr, "dto_create: bad dimensions");
+    if (d->dt_idx < 0 || d->dt_idx >= d->z)
+        return fail(nullptr, "dto_create: the timestep must be a trajectory component (bilinear_integrator.jl:123)");
+    if (!d->Z0) return fail(nullptr, "dto_create: Z0 is required (constraint patterns are taken at Z0)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, "dto_create: no HIP device available (the engine has no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev) return fail(nullptr, "dto_create: bad device ordinal");
+
+    dto_handle* h = new dto_handle();
+    try {
+        h->device = d->device;
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipStreamCreate(&h->stream));
+        h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
+        h->eval_hessian = d->eval_hessian;
+        h->n_vars = (int64_t)d->z * d->N + d->gd;
+        h->k_lo = d->k_lo > 0 ? d->k_lo : 1;
+        h->k_hi = d->k_hi > 0 ? d->k_hi : d->N;
+        if (h->k_lo > h->k_hi || h->k_hi > h->N) throw HipError{"dto_create: bad knot shard"};
+
+        // integrators: rows stacked in list order (evaluator.jl:211-217)
+        int pre = 0;
+        int64_t row = 0;
+        for (int i = 0; i < d->n_integrators; ++i) {
+            const dto_integrator_desc& s = d->integrators[i];
+            if (s.x_dim < 1 || s.x_off < 0 || s.x_off + s.x_dim > d->z) throw HipError{"integrator: bad state range"};
+            h->integ_kind.push_back(s.kind);
+            h->integ_dim.push_back(s.x_dim);
+            h->integ_row_off.push_back(row);
+            if (s.kind == DTO_INTEGRATOR_BILINEAR) {
+                if (s.u_dim < 0 || s.u_dim > MAX_DRIVES) throw HipError{"bilinear integrator: supports 0..7 drives"};
+                if (s.u_dim > 0 && (s.u_off < 0 || s.u_off + s.u_dim > d->z)) throw HipError{"bilinear integrator: bad control range"};
+                if (!s.G) throw HipError{"bilinear integrator: G is null"};
+                BilHost b;
+                b.k.n = s.x_dim; b.k.m = s.u_dim; b.k.npad = pad64(s.x_dim);
+                b.k.x_off = s.x_off; b.k.u_off = s.u_off; b.k.pre = pre; b.k.row_off = row;
+                const int n = s.x_dim, np = b.k.npad, m1 = s.u_dim + 1;
+                std::vector<double> G((size_t)m1 * np * np, 0.0), GT((size_t)m1 * np * np, 0.0);
+                b.g1.assign(m1, 0.0);
+                for (int j = 0; j < m1; ++j)
+                    for (int c = 0; c < n; ++c) {
+                        double cs = 0.0;
+                        for (int r = 0; r < n; ++r) {
+                            const double v = s.G[(size_t)j * n * n + (size_t)c * n + r];
+                            G[(size_t)j * np * np + (size_t)c * np + r] = v;
+                            GT[(size_t)j * np * np + (size_t)r * np + c] = v;
+                            cs += std::fabs(v);
+                        }
+                        b.g1[j] = std::max(b.g1[j], cs);
+                    }
+                b.k.G = own(h, dupload(G));
+                b.k.GT = own(h, dupload(GT));
+                h->integ_index.push_back((int)h->bil.size());
+                h->bil.push_back(std::move(b));
+            } else if (s.kind == DTO_INTEGRATOR_DERIVATIVE) {
+                if (s.u_off < 0 || s.u_off + s.x_dim > d->z) throw HipError{"derivative integrator: bad derivative range"};
+                KDer k{};
+                k.d = s.x_dim; k.x_off = s.x_off; k.xdot_off = s.u_off; k.pre = pre; k.row_off = row;
+                h->integ_index.push_back((int)h->der.size());
+                h->der.push_back(k);
+            } else {
+                throw HipError{"unknown integrator kind (TimeDependentBilinearIntegrator and user integrators stay on the host)"};
+            }
+            pre += s.x_dim;
+            row += (int64_t)s.x_dim * h->K;
+        }
+        h->D = pre;
+        h->n_dyn = row;
+
+        // nonlinear knot constraints: rows follow the dynamics (evaluator.jl:219-223)
+        for (int i = 0; i < d->n_constraints; ++i) {
+            const dto_constraint_desc& s = d->constraints[i];
+            if (s.kind != DTO_CONSTRAINT_NORM_MINUS_C && s.kind != DTO_CONSTRAINT_SQNORM_MINUS_C)
+                throw HipError{"unknown constraint kind (closure-based constraints stay on the host)"};
+            if (s.n_comps < 1 || !s.comps || (!s.times && s.n_times > 0)) throw HipError{"constraint: bad description"};
+            ConHost c;
+            c.k.kind = s.kind; c.k.n_comps = s.n_comps; c.k.c = s.c;
+            c.equality = s.equality;
+            c.comps.assign(s.comps, s.comps + s.n_comps);
+            for (int q : c.comps)
+                if (q < 0 || q >= d->z) throw HipError{"constraint: component out of range"};
+            c.n_times_total = s.n_times;
+            for (int64_t t = 0; t < s.n_times; ++t) {
+                if (s.times[t] < 1 || s.times[t] > d->N) throw HipError{"constraint: time out of range"};
+                c.times0.push_back(s.times[t] - 1);
+            }
+            c.row_off = row;
+            row += s.n_times;  // g_dim = 1
+            h->con.push_back(std::move(c));
+        }
+        h->n_cons = row;
+
+        // shard
+        KProb& P = h->P;
+        P.N = h->N; P.K = h->K; P.z = h->z; P.dt_idx = h->dt_idx; P.D = h->D;
+        P.kn_lo = h->k_lo - 1;
+        P.n_knots = h->k_hi - h->k_lo + 1;
+        P.n_int = std::max<int64_t>(0, std::min<int64_t>(h->k_hi, h->K) - h->k_lo + 1);
+
+        build_structure(h, d->Z0);
+        h->d_colptr = own(h, dupload(h->colptr));
+        P.colptr = h->d_colptr;
+        const int64_t c_lo = P.kn_lo * h->z, c_hi = (P.kn_lo + P.n_knots) * h->z;
+        P.jac_lo = h->colptr[c_lo];
+        P.hess_lo = hess_block_start(h, P.kn_lo);
+        P.grad_lo = c_lo;
+        dto_shard_info& I = h->info;
+        I.k_lo = h->k_lo; I.k_hi = h->k_hi;
+        I.n_vars = h->n_vars; I.n_cons = h->n_cons; I.jac_nnz = h->jac_nnz; I.hess_nnz = h->hess_nnz;
+        I.grad_lo = c_lo;
+        I.grad_len = c_hi - c_lo + (h->k_hi == h->N ? h->gd : 0);
+        I.jac_lo = P.jac_lo;
+        I.jac_len = h->colptr[c_hi] - P.jac_lo;
+        I.hess_lo = P.hess_lo;
+        I.hess_len = hess_block_start(h, P.kn_lo + P.n_knots) - P.hess_lo;
+
+        // local constraint rows: integrators first, then constraints
+        int64_t lrow = 0;
+        for (size_t i = 0; i < h->integ_kind.size(); ++i) {
+            const int dd = h->integ_dim[i];
+            if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) h->bil[h->integ_index[i]].k.lrow_off = lrow;
+            else h->der[h->integ_index[i]].lrow_off = lrow;
+            if (P.n_int > 0) h->row_segments.emplace_back(h->integ_row_off[i] + P.kn_lo * dd, P.n_int * dd);
+            lrow += P.n_int * dd;
+        }
+        for (auto& c : h->con) {
+            std::vector<int64_t> times, lrows, tidx, jpos;
+            for (int64_t i = 0; i < c.n_times_total; ++i) {
+                const int64_t kn = c.times0[i];
+                if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
+                if (!h->row_segments.empty() && !times.empty() && tidx.back() == i - 1 &&
+                    h->row_segments.back().first + h->row_segments.back().second == c.row_off + i)
+                    h->row_segments.back().second += 1;
+                else
+                    h->row_segments.emplace_back(c.row_off + i, 1);
+                times.push_back(kn);
+                lrows.push_back(lrow++);
+                tidx.push_back(i);
+                for (size_t q = 0; q < c.comps.size(); ++q) {
+                    const int64_t col = kn * h->z + c.comps[q];
+                    int64_t pos = -1;
+                    const size_t lo = con_lower(h, col);
+                    for (size_t e = lo; e < h->con_cols.size() && h->con_cols[e] == col; ++e)
+                        if (h->con_rows[e] == c.row_off + i) {
+                            pos = h->colptr[col] + (int64_t)h->D * col_cnt(h, kn) + (int64_t)(e - lo) - P.jac_lo;
+                            break;
+                        }
+                    jpos.push_back(pos);
+                }
+            }
+            c.k.n_times = (int64_t)times.size();
+            c.k.mu_off = c.row_off;
+            c.k.comps = own(h, dupload(c.comps));
+            c.k.times = own(h, dupload(times));
+            c.k.lrow = own(h, dupload(lrows));
+            c.k.tidx = own(h, dupload(tidx));
+            c.k.jpos = own(h, dupload(jpos));
+        }
+        h->cons_len = lrow;
+        I.cons_len = lrow;
+        I.n_row_segments = (int32_t)h->row_segments.size();
+
+        // objectives
+        for (int i = 0; i < d->n_objectives; ++i) {
+            const dto_objective_desc& s = d->objectives[i];
+            KObj o{};
+            o.kind = s.kind; o.weight = s.weight; o.D = s.D;
+            std::vector<int64_t> times;
+            if (s.kind == DTO_OBJECTIVE_MINIMUM_TIME) {
+                for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn)
+                    if (kn < h->K) times.push_back(kn);
+            } else if (s.kind == DTO_OBJECTIVE_QUADRATIC_REGULARIZER || s.kind == DTO_OBJECTIVE_LINEAR_REGULARIZER) {
+                if (s.comp_dim < 1 || s.comp_off < 0 || s.comp_off + s.comp_dim > d->z || !s.R)
+                    throw HipError{"objective: bad component range"};
+                o.comp_off = s.comp_off; o.comp_dim = s.comp_dim;
+                o.R = own(h, dupload(std::vector<double>(s.R, s.R + s.comp_dim)));
+                if (s.baseline && s.kind == DTO_OBJECTIVE_QUADRATIC_REGULARIZER) {
+                    o.has_baseline = 1;
+                    o.baseline = own(h, dupload(std::vector<double>(s.baseline, s.baseline + (size_t)s.comp_dim * d->N)));
+                }
+                if (s.times) {
+                    for (int64_t t = 0; t < s.n_times; ++t) {
+                        if (s.times[t] < 1 || s.times[t] > d->N) throw HipError{"objective: time out of range"};
+                        const int64_t kn = s.times[t] - 1;
+                        if (kn >= P.kn_lo && kn < P.kn_lo + P.n_knots) times.push_back(kn);
+                    }
+                } else {
+                    for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) times.push_back(kn);
+                }
+            } else {
+                throw HipError{"unknown objective kind (closure-based objectives stay on the host)"};
+            }
+            o.n_times = (int64_t)times.size();
+            o.times = own(h, dupload(times));
+            h->obj.push_back(o);
+        }
+
+        // scratch
+        h->d_Z = own(h, dalloc<double>(h->n_vars));
+        h->d_mu = own(h, dalloc<double>(std::max<int64_t>(h->n_cons, 1)));
+        h->d_partial = own(h, dalloc<double>(256));
+        h->d_f = own(h, dalloc<double>(1));
+        h->d_bounds = own(h, dalloc<double>(2));
+        HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 4 * sizeof(double)));
+
+        // per-bilinear workspaces + generator product norms (for the step-budget bounds)
+        for (auto& b : h->bil) {
+            const int m = b.k.m;
+            const int T_fw = d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m;
+            if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for second-order sweep (max 4 with eval_hessian)"};
+            alloc_sweep(h, b, b.fw, T_fw, false);
+            if (d->eval_hessian) alloc_sweep(h, b, b.ad, 1 + m, true);
+            const int npad = b.k.npad;
+            alloc_chain(h, b, std::max(chunk_size(h, npad), (m + 1) * (m + 1)));
+            // N2[i][j] = ||G_i G_j||_1 with the engine's own batched GEMM + norm kernels
+            const int m1 = m + 1, nb = m1 * m1;
+            const size_t nn = (size_t)npad * npad;
+            for (int i = 0; i < m1; ++i)
+                for (int j = 0; j < m1; ++j) {
+                    HIP_CHECK(hipMemcpyAsync(b.chain.W[0] + (size_t)(i * m1 + j) * nn, b.k.G + (size_t)i * nn, nn * 8, hipMemcpyDeviceToDevice, h->stream));
+                    HIP_CHECK(hipMemcpyAsync(b.chain.W[2] + (size_t)(i * m1 + j) * nn, b.k.G + (size_t)j * nn, nn * 8, hipMemcpyDeviceToDevice, h->stream));
+                }
+            launch_bgemm_plain(h->stream, npad, nb, b.chain.W[0], b.chain.W[2], b.chain.W[1]);
+            launch_norm1(h->stream, npad, nb, b.chain);
+            std::vector<double> norms((size_t)nb * 4);
+            HIP_CHECK(hipMemcpyAsync(norms.data(), b.chain.norms, norms.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            b.n2.resize(nb);
+            for (int i = 0; i < nb; ++i) b.n2[i] = norms[(size_t)i * 4 + 1];
+            b.d_g1 = own(h, dupload(b.g1));
+            b.d_n2 = own(h, dupload(b.n2));
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+    } catch (const HipError& e) {
+        g_create_error = e.msg;
+        delete h;
+        return 1;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        delete h;
+        return 1;
+    }
+    *out = h;
+    return 0;
+}
+
+int dto_num_vars(const dto_handle* h, int64_t* out) { if (!h || !out) return 1; *out = h->n_vars; return 0; }
+int dto_num_cons(const dto_handle* h, int64_t* out) { if (!h || !out) return 1; *out = h->n_cons; return 0; }
+int dto_num_dynamics_cons(const dto_handle* h, int64_t* out) { if (!h || !out) return 1; *out = h->n_dyn; return 0; }
+int dto_jac_nnz(const dto_handle* h, int64_t* out) { if (!h || !out) return 1; *out = h->jac_nnz; return 0; }
+int dto_hess_nnz(const dto_handle* h, int64_t* out) { if (!h || !out) return 1; *out = h->hess_nnz; return 0; }
+int dto_features_available(const dto_handle* h, int32_t* grad, int32_t* jac, int32_t* hess) {
+    if (!h) return 1;
+    if (grad) *grad = 1;
+    if (jac) *jac = 1;
+    if (hess) *hess = h->eval_hessian ? 1 : 0;
+    return 0;
+}
+int dto_get_shard_info(const dto_handle* h, dto_shard_info* out) { if (!h || !out) return 1; *out = h->info; return 0; }
+int dto_shard_rows(const dto_handle* h, int64_t* start1, int64_t* len) {
+    if (!h || !start1 || !len) return 1;
+    for (size_t i = 0; i < h->row_segments.size(); ++i) {
+        start1[i] = h->row_segments[i].first + 1;
+        len[i] = h->row_segments[i].second;
+    }
+    return 0;
+}
+
+int dto_jacobian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols) {
+    if (!h || !rows || !cols || first < 0 || count < 0 || first + count > h->jac_nnz) return 1;
+    if (count == 0) return 0;
+    // column containing `first`
+    int64_t c = std::upper_bound(h->colptr.begin(), h->colptr.end(), first) - h->colptr.begin() - 1;
+    int64_t written = 0;
+    const int64_t nzcols = h->N * h->z;
+    for (; c < nzcols && written < count; ++c) {
+        const int64_t kn = c / h->z;
+        int64_t pos = h->colptr[c];
+        auto emit = [&](int64_t row0) {
+            if (pos >= first && written < count) {
+                rows[written] = row0 + 1;
+                cols[written] = c + 1;
+                ++written;
+            }
+            ++pos;
+        };
+        // integrator rows: for each integrator, interval kn-1 then interval kn
+        for (size_t i = 0; i < h->integ_kind.size(); ++i) {
+            const int d = h->integ_dim[i];
+            const int64_t off = h->integ_row_off[i];
+            if (kn >= 1) for (int r = 0; r < d; ++r) emit(off + (kn - 1) * d + r);
+            if (kn < h->K) for (int r = 0; r < d; ++r) emit(off + kn * d + r);
+        }
+        for (size_t e = con_lower(h, c); e < h->con_cols.size() && h->con_cols[e] == c; ++e) emit(h->con_rows[e]);
+    }
+    return written == count ? 0 : 1;
+}
+
+int dto_hessian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols) {
+    if (!h || !rows || !cols || first < 0 || count < 0 || first + count > h->hess_nnz) return 1;
+    if (count == 0) return 0;
+    const int64_t z = h->z, tri = z * (z + 1) / 2, blk = z * z + tri;
+    int64_t kn = first < tri ? 0 : 1 + (first - tri) / blk;
+    int64_t written = 0;
+    for (; kn < h->N && written < count; ++kn) {
+        int64_t pos = hess_block_start(h, kn);
+        for (int b = 0; b < z && written < count; ++b) {
+            const int64_t c = kn * z + b;
+            auto emit = [&](int64_t row0) {
+                if (pos >= first && written < count) {
+                    rows[written] = row0 + 1;
+                    cols[written] = c + 1;
+                    ++written;
+                }
+                ++pos;
+            };
+            if (kn >= 1) for (int a = 0; a < z; ++a) emit((kn - 1) * z + a);
+            for (int a = 0; a <= b; ++a) emit(kn * z + a);
+        }
+    }
+    return written == count ? 0 : 1;
+}
+
+int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper) {
+    if (!h || !lower || !upper) return 1;
+    for (int64_t i = 0; i < h->n_cons; ++i) { lower[i] = 0.0; upper[i] = 0.0; }
+    for (auto& c : h->con)
+        if (!c.equality)
+            for (int64_t i = 0; i < c.n_times_total; ++i) lower[c.row_off + i] = -std::numeric_limits<double>::infinity();
+    return 0;
+}
+
+// ---- device-pointer callbacks
+int dto_eval_objective_dev(dto_handle* h, const double* dZ, double* df, void* stream) {
+    return guarded(h, [&] { do_objective(h, dZ, df, (hipStream_t)stream); });
+}
+int dto_eval_gradient_dev(dto_handle* h, const double* dZ, double* dgrad, void* stream) {
+    return guarded(h, [&] { do_gradient(h, dZ, dgrad, (hipStream_t)stream); });
+}
+int dto_eval_constraint_dev(dto_handle* h, const double* dZ, double* dg, void* stream) {
+    return guarded(h, [&] { do_constraint(h, dZ, dg, (hipStream_t)stream); });
+}
+int dto_eval_jacobian_dev(dto_handle* h, const double* dZ, double* dvals, void* stream) {
+    return guarded(h, [&] { do_jacobian(h, dZ, dvals, (hipStream_t)stream); });
+}
+int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dvals, void* stream) {
+    return guarded(h, [&] {
+        if (!h->eval_hessian) throw HipError{"handle was created with eval_hessian = 0"};
+        do_hessian(h, dZ, sigma, dmu, dvals, (hipStream_t)stream);
+    });
+}
+
+// ---- host-pointer callbacks (blocking)
+int dto_eval_objective(dto_handle* h, const double* Z, double* f) {
+    return guarded(h, [&] {
+        upload_Z(h, Z);
+        do_objective(h, h->d_Z, h->d_f, h->stream);
+        HIP_CHECK(hipMemcpyAsync(f, h->d_f, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+int dto_eval_gradient(dto_handle* h, const double* Z, double* grad) {
+    return guarded(h, [&] {
+        upload_Z(h, Z);
+        double* o = staging(h, (size_t)h->info.grad_len);
+        do_gradient(h, h->d_Z, o, h->stream);
+        HIP_CHECK(hipMemcpyAsync(grad, o, sizeof(double) * (size_t)h->info.grad_len, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+int dto_eval_constraint(dto_handle* h, const double* Z, double* g) {
+    return guarded(h, [&] {
+        upload_Z(h, Z);
+        double* o = staging(h, (size_t)h->cons_len);
+        do_constraint(h, h->d_Z, o, h->stream);
+        HIP_CHECK(hipMemcpyAsync(g, o, sizeof(double) * (size_t)h->cons_len, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        check_sweeps(h);
+    });
+}
+int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals) {
+    return guarded(h, [&] {
+        upload_Z(h, Z);
+        double* o = staging(h, (size_t)h->info.jac_len);
+        do_jacobian(h, h->d_Z, o, h->stream);
+        HIP_CHECK(hipMemcpyAsync(vals, o, sizeof(double) * (size_t)h->info.jac_len, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        check_sweeps(h);
+    });
+}
+int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double* mu, double* vals) {
+    return guarded(h, [&] {
+        if (!h->eval_hessian) throw HipError{"handle was created with eval_hessian = 0"};
+        upload_Z(h, Z);
+        HIP_CHECK(hipMemcpyAsync(h->d_mu, mu, sizeof(double) * (size_t)h->n_cons, hipMemcpyHostToDevice, h->stream));
+        double* o = staging(h, (size_t)h->info.hess_len);
+        do_hessian(h, h->d_Z, sigma, h->d_mu, o, h->stream);
+        HIP_CHECK(hipMemcpyAsync(vals, o, sizeof(double) * (size_t)h->info.hess_len, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        check_sweeps(h);
+    });
+}
+
+int dto_eval_jacobian_product(dto_handle* h, const double*, const double*, double*) {
+    return fail(h, "dto_eval_jacobian_product: not implemented yet (SURVEY.md §8f rank 1)");
+}
+int dto_eval_jacobian_transpose_product(dto_handle* h, const double*, const double*, double*) {
+    return fail(h, "dto_eval_jacobian_transpose_product: not implemented yet (SURVEY.md §8f rank 1)");
+}
+
+// ---- measurement
+int dto_profile_enable(dto_handle* h, int32_t on) { if (!h) return 1; h->profiling = on != 0; return 0; }
+int dto_profile_reset(dto_handle* h) {
+    if (!h) return 1;
+    for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    h->prof.clear();
+    return 0;
+}
+int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops) {
+    return guarded(h, [&] {
+        int cat = -1;
+        if (!strcmp(name, "bgemm")) cat = CAT_BGEMM;
+        else if (!strcmp(name, "expmv")) cat = CAT_SWEEP;
+        else if (strcmp(name, "all")) throw HipError{"dto_profile_get: unknown name"};
+        double tot = 0, fl = 0;
+        int64_t n = 0;
+        for (auto& r : h->prof) {
+            if (cat >= 0 && r.cat != cat) continue;
+            HIP_CHECK(hipEventSynchronize(r.b));
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+            tot += t; fl += r.flops; ++n;
+        }
+        if (ms) *ms = tot;
+        if (launches) *launches = n;
+        if (flops) *flops = fl;
+    });
+}
+int dto_last_stats(const dto_handle* h, int32_t* max_squarings, int32_t* expmv_terms) {
+    if (!h) return 1;
+    dto_handle* hm = const_cast<dto_handle*>(h);
+    int rc = guarded(hm, [&] { HIP_CHECK(hipDeviceSynchronize()); check_sweeps(hm); });
+    if (max_squarings) *max_squarings = h->last_smax;
+    if (expmv_terms) *expmv_terms = h->last_terms;
+    return rc;
+}
+
+}  // extern "C"

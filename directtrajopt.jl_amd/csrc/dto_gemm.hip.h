@@ -1,0 +1,169 @@
+// dto_gemm.hip.h -- workgroup-level FP64 MFMA GEMM core for gfx950 (CDNA4).
+//
+// One 256-thread workgroup (4 wavefronts of 64, one per SIMD) computes a TM x TN tile of
+// C = A * B for COLUMN-MAJOR operands.  The wave grid is 2 x 2, each wave owns a
+// (TM/2) x (TN/2) sub-tile made of 16x16 `v_mfma_f64_16x16x4_f64` accumulators.
+//
+// The product is issued TRANSPOSED (MFMA a-operand <- B fragment, b-operand <- A fragment) so
+// that the accumulator's lane index runs along C's rows: lane l, register r of accumulator
+// (ti,tj) holds C[row0 + 16*ti + (l&15)][col0 + 16*tj + (l>>4) + 4*r].  Sixteen consecutive lanes
+// therefore touch 128 contiguous bytes of a column-major C, which is what the epilogues store.
+//
+// LDS staging (double buffered, one barrier per 16-deep K panel):
+//   As[k][m]  : KB rows of TM doubles, row pitch TM+16  (2*(TM+16) mod 64 == 32 -> the two k's of a
+//               32-lane ds_read_b64 group land on disjoint bank halves: conflict-free)
+//   Bs[n][k]  : TN rows of KB doubles, row pitch KB+2   (36*c mod 64 distinct for c<16: conflict-free)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dto {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int GEMM_KB = 16;
+constexpr int GEMM_THREADS = 256;
+
+template <int TM, int TN>
+struct GemmCfg {
+    static constexpr int KB = GEMM_KB;
+    static constexpr int LDA_S = TM + 16;
+    static constexpr int LDB_S = KB + 2;
+    static constexpr int AS_ELEMS = KB * LDA_S;
+    static constexpr int BS_ELEMS = TN * LDB_S;
+    static constexpr int SMEM_DOUBLES = 2 * (AS_ELEMS + BS_ELEMS);
+    static constexpr int MT = TM / 32;  // accumulator tiles per wave along rows
+    static constexpr int NT = TN / 32;  // along columns
+    static constexpr int A_LD = (TM * KB / 2) / GEMM_THREADS;  // double2 loads per thread per panel
+    static constexpr int B_LD = (TN * KB / 2) / GEMM_THREADS;
+};
+
+template <int TM, int TN>
+struct GemmAcc {
+    d4 v[GemmCfg<TM, TN>::MT][GemmCfg<TM, TN>::NT];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < GemmCfg<TM, TN>::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < GemmCfg<TM, TN>::NT; ++j) v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+};
+
+// acc += A[0:TM, 0:Klen] * diag-scaled B[0:Klen, 0:TN]
+//   A      : pointer to the tile's first row, column 0 of the K range (column-major, lda)
+//   B      : pointer to row 0 of the K range, the tile's first column (column-major, ldb)
+//   colscale : nullptr, or TN per-column factors applied to B (b[k][n] *= colscale[n])
+//   Klen   : multiple of 16
+// All 256 threads must call it; it ends with a barrier so LDS may be reused immediately.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const double* __restrict__ A,
+                                                int lda, const double* __restrict__ B, int ldb, int Klen,
+                                                const double* __restrict__ colscale, double* smem) {
+    using C = GemmCfg<TM, TN>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    double* As = smem;
+    double* Bs = smem + 2 * C::AS_ELEMS;
+
+    d2 ra[C::A_LD], rb[C::B_LD];
+    int a_k[C::A_LD], a_m[C::A_LD], b_n[C::B_LD], b_k[C::B_LD];
+    double bsc[C::B_LD];
+#pragma unroll
+    for (int i = 0; i < C::A_LD; ++i) {
+        const int idx = tid + GEMM_THREADS * i;
+        a_k[i] = idx / (TM / 2);
+        a_m[i] = 2 * (idx % (TM / 2));
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_LD; ++i) {
+        const int idx = tid + GEMM_THREADS * i;
+        b_n[i] = idx / (C::KB / 2);
+        b_k[i] = 2 * (idx % (C::KB / 2));
+        bsc[i] = colscale ? colscale[b_n[i]] : 1.0;
+    }
+
+    const int nkb = Klen / C::KB;
+
+    auto load_panel = [&](int kb) {
+        const int k0 = kb * C::KB;
+#pragma unroll
+        for (int i = 0; i < C::A_LD; ++i)
+            ra[i] = *reinterpret_cast<const d2*>(A + (size_t)(k0 + a_k[i]) * lda + a_m[i]);
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i)
+            rb[i] = *reinterpret_cast<const d2*>(B + (size_t)b_n[i] * ldb + k0 + b_k[i]);
+    };
+    auto store_panel = [&](int buf) {
+        double* as = As + buf * C::AS_ELEMS;
+        double* bs = Bs + buf * C::BS_ELEMS;
+#pragma unroll
+        for (int i = 0; i < C::A_LD; ++i)
+            *reinterpret_cast<d2*>(as + a_k[i] * C::LDA_S + a_m[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+            d2 v = rb[i];
+            v.x *= bsc[i];
+            v.y *= bsc[i];
+            *reinterpret_cast<d2*>(bs + b_n[i] * C::LDB_S + b_k[i]) = v;
+        }
+    };
+
+    load_panel(0);
+    store_panel(0);
+    __syncthreads();
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) load_panel(kb + 1);
+        const double* as = As + buf * C::AS_ELEMS + wm * (TM / 2) + lr;
+        const double* bs = Bs + buf * C::BS_ELEMS + (wn * (TN / 2) + lr) * C::LDB_S;
+#pragma unroll
+        for (int kk = 0; kk < C::KB; kk += 4) {
+            double af[C::MT], bf[C::NT];
+#pragma unroll
+            for (int ti = 0; ti < C::MT; ++ti) af[ti] = as[(kk + lq) * C::LDA_S + 16 * ti];
+#pragma unroll
+            for (int tj = 0; tj < C::NT; ++tj) bf[tj] = bs[16 * tj * C::LDB_S + kk + lq];
+#pragma unroll
+            for (int ti = 0; ti < C::MT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < C::NT; ++tj)
+                    acc.v[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[tj], af[ti], acc.v[ti][tj], 0, 0, 0);
+        }
+        if (kb + 1 < nkb) store_panel(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// Coordinates of the calling lane's accumulator elements inside the TM x TN tile.
+template <int TM, int TN>
+struct GemmCoord {
+    int row_base;  // + 16*ti
+    int col_base;  // + 16*tj + 4*r
+    __device__ __forceinline__ GemmCoord() {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        row_base = (wave >> 1) * (TM / 2) + (lane & 15);
+        col_base = (wave & 1) * (TN / 2) + (lane >> 4);
+    }
+};
+
+// XCD-aware decode of a 1-D grid into (batch, tile).  Workgroups b and b+8 share an XCD under the
+// observed round-robin dispatch, so the tiles of one matrix are given ids that differ by multiples
+// of 8 and sit next to each other in dispatch order: they then re-use each other's A/B panels from
+// the same XCD's L2.  Placement only affects speed, never correctness.
+__device__ __forceinline__ bool decode_batch_tile(int nbatch, int tiles_per_mat, int& batch, int& tile) {
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7;
+    const int idx = wg >> 3;
+    batch = (idx / tiles_per_mat) * 8 + xcd;
+    tile = idx % tiles_per_mat;
+    return batch < nbatch;
+}
+inline int batch_tile_grid(int nbatch, int tiles_per_mat) { return ((nbatch + 7) / 8) * 8 * tiles_per_mat; }
+
+}  // namespace dto

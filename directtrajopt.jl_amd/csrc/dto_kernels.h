@@ -1,0 +1,167 @@
+// dto_kernels.h -- launch interface between the host engine (dto_engine.cpp) and the HIP kernels
+// (dto_kernels.hip).  Plain structs passed by value to kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dto {
+
+constexpr int TAYLOR_M = 16;                 // degree of the matrix Taylor polynomial
+constexpr double THETA_16 = 0.78028743;      // backward-error radius of T_16 in double (Al-Mohy & Higham 2011, Table 3.1 method)
+constexpr int COEF_STRIDE = 20;              // doubles per interval in the coefficient table
+constexpr int MAX_TYPES = 16;                // column types of a generator sweep (p, d^i, h^{ij})
+constexpr int MAX_DRIVES = 7;
+
+// Problem-level constants every kernel may need.
+struct KProb {
+    int64_t N, K;       // knots, intervals (K = N-1)
+    int32_t z, dt_idx;  // components per knot, timestep component
+    int32_t D;          // sum of integrator state dims (Jacobian rows per interval)
+    int32_t pad0;
+    int64_t kn_lo;      // first owned knot (0-based)
+    int64_t n_knots;    // owned knots
+    int64_t n_int;      // owned intervals: knots kn_lo .. kn_lo+n_int-1 (each < K)
+    const int64_t* colptr;  // device, global Jacobian column pointers (0-based), n_vars+1
+    int64_t jac_lo;     // first Jacobian value owned
+    int64_t hess_lo;    // first Hessian value owned
+    int64_t grad_lo;    // first gradient entry owned (= kn_lo*z)
+};
+
+// One BilinearIntegrator (src/integrators/bilinear_integrator.jl:61-85) on the device.
+struct KBil {
+    int32_t n, m, npad;
+    int32_t x_off, u_off;
+    int32_t pre;          // rows of earlier integrators per interval
+    int64_t row_off;      // 0-based global row offset of the integrator (evaluator.jl:213-217)
+    int64_t lrow_off;     // offset of its rows inside the shard-local constraint buffer
+    const double* G;      // (m+1) padded npad x npad generators, column-major
+    const double* GT;     // their transposes
+};
+
+struct KDer {  // DerivativeIntegrator (derivative_integrator.jl:26-49)
+    int32_t d, x_off, xdot_off, pre;
+    int64_t row_off, lrow_off;
+};
+
+// position (inside the shard-local value slab) of Jacobian entry (row r of integrator block,
+// column `comp` of knot kn); part 0 = rows of interval kn-1, part 1 = rows of interval kn.
+__host__ __device__ inline int64_t jac_pos(const KProb& P, const int64_t* colptr, int64_t kn, int comp,
+                                           int pre, int d_i, int part, int r) {
+    const int has_prev = kn >= 1, has_own = kn < P.K;
+    const int cnt = has_prev + has_own;
+    return colptr[kn * P.z + comp] + (int64_t)pre * cnt + ((part == 1 && has_prev) ? d_i : 0) + r - P.jac_lo;
+}
+
+// position of upper-triangular Hessian entry (a <= b, knot-local comps) of diagonal block kn
+__host__ __device__ inline int64_t hess_pos(const KProb& P, int64_t kn, int a, int b) {
+    const int64_t z = P.z;
+    const int64_t tri = z * (z + 1) / 2;
+    int64_t colstart;
+    if (kn == 0)
+        colstart = (int64_t)b * (b + 1) / 2;
+    else
+        colstart = tri + (kn - 1) * (z * z + tri) + (int64_t)b * z + (int64_t)b * (b + 1) / 2 + z;
+    return colstart + a - P.hess_lo;
+}
+
+struct TypeDesc {     // one column type of a generator sweep
+    int32_t n_extra;  // extra segments G_gen * Z_src * scaleE * mult
+    int32_t gen[2];
+    int32_t src[2];
+    double mult[2];
+};
+
+struct SweepTypes {
+    int32_t T;
+    TypeDesc t[MAX_TYPES];
+};
+
+// ------------------------------------------------------------------ launch wrappers (dto_kernels.hip)
+struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices npad x npad each
+    double* W[6];    // A, A2, A3, A4, Ha, Hb
+    double* norms;   // [C][4]
+    double* coef;    // [C][COEF_STRIDE]
+    int32_t* s;      // [C] squarings per interval
+    int32_t* smax;   // [1] max over the call (stats)
+};
+
+void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, int64_t int0, int nb, double* A);
+void launch_bgemm_plain(hipStream_t st, int npad, int nb, const double* A, const double* Bm, double* C);
+void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w);
+void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w);
+void launch_poly_h3(hipStream_t st, int npad, int nb, const ChainWork& w);
+void launch_bgemm_horner(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int coef_base);
+void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
+                         const KProb& P, const KBil& B, int64_t int0, double* vals);
+
+struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear integrator
+    int32_t npad, Kpad, TN;   // Kpad multiple of TN
+    double* Z[2];      // [T][Kpad][npad] ping-pong terms
+    double* S;         // [T][Kpad][npad] sums
+    double* GY;        // [Kpad][npad]   G(u) * S0
+    double* W;         // [(m+1)][Kpad][npad]  G_j' mu   (Hessian)
+    double* scaleA;    // [(m+1)][Kpad]  dt*ubar_j/q
+    double* scaleU;    // [(m+1)][Kpad]  ubar_j
+    double* scaleE;    // [Kpad]         dt/q
+    unsigned long long* termnorm;  // [3][T][Kpad]
+    unsigned long long* sumnorm;   // [T][Kpad]
+    int32_t* active;   // [Kpad/TN]
+    int32_t* stats;    // [0] active blocks after the last check, [1] terms used (max)
+};
+
+// src_kind: 0 = state x_k of the integrator (forward sweep), 1 = multipliers mu_k (adjoint sweep)
+void launch_sweep_init(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
+                       const double* dZ, const double* dmu, int src_kind, int q);
+void launch_sweep_restart(hipStream_t st, const SweepBuf& w, int T);
+void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
+                       int t, int in_buf);
+void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);
+// out[j] = G_j (or G_j') * V for every generator j (no summation): out [(m+1)][Kpad][npad]
+void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
+                             double* out);
+// GY = sum_j ubar_j G_j (or G_j') * V
+void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V, double* out);
+
+void launch_cons_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const double* dZ, double* g);
+void launch_cons_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dZ, double* g);
+void launch_jac_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, double* vals);
+void launch_jac_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dZ, double* vals);
+
+struct KCon {  // NonlinearKnotPointConstraint with a built-in g
+    int32_t kind, n_comps;
+    double c;
+    const int32_t* comps;    // device [n_comps]
+    const int64_t* times;    // device, owned 0-based knots [n_times]
+    const int64_t* lrow;     // device, local row of each owned time in the shard-local g buffer
+    const int64_t* jpos;     // device [n_times][n_comps] local Jacobian positions (-1: not in pattern)
+    int64_t n_times;
+    int64_t mu_off;          // global 0-based row of the constraint's first row (for mu), evaluator.jl:219-223
+    const int64_t* tidx;     // device, index of each owned time inside the constraint's full `times`
+};
+void launch_cons_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* g);
+void launch_jac_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* vals);
+void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* dmu, double* H);
+
+struct KObj {  // objective term
+    int32_t kind, comp_off, comp_dim, has_baseline;
+    double weight, D;
+    const double* R;         // device [comp_dim]
+    const double* baseline;  // device [comp_dim x N] or null
+    const int64_t* times;    // device, owned 0-based knots
+    int64_t n_times;
+};
+void launch_objective(hipStream_t st, const KProb& P, const KObj& O, const double* dZ, double* partial, double* f);
+void launch_gradient(hipStream_t st, const KProb& P, const KObj& O, const double* dZ, double* grad);
+void launch_hess_objective(hipStream_t st, const KProb& P, const KObj& O, const double* dZ, double sigma, double* H);
+void launch_hess_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dmu, double* H);
+void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad,
+                          const double* dmu, double* H);
+
+void launch_fill(hipStream_t st, double* p, int64_t n, double v);
+// out2[0] = max_k min(b1_k, b2_k), out2[1] = max_k b1_k (bit patterns of non-negative doubles), where
+// b1_k >= ||A_k||_1 and b2_k >= ||A_k^2||_1^(1/2) follow from the generator norms g1[j] = ||G_j||_1,
+// n2[i][j] = ||G_i G_j||_1 and the triangle inequality.
+void launch_norm_bounds(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, const double* g1,
+                        const double* n2, unsigned long long* out2);
+
+}  // namespace dto

@@ -1,0 +1,233 @@
+"""``Evaluator`` -- mirror of the reference's ``Solvers.Evaluator <: MOI.AbstractNLPEvaluator``
+(src/solvers/evaluator.jl:66-98, 291-456) on top of the C ABI.  Method names follow MOI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import library_path, load_library  # noqa: F401
+from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, LinearRegularizer,
+                      MinimumTimeObjective, NonlinearKnotPointConstraint, NullObjective, QuadraticRegularizer)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(capi.c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(capi.c_int64_p)
+
+
+def _flatten_objective(obj):
+    if obj is None or isinstance(obj, NullObjective):
+        return []
+    if isinstance(obj, CompositeObjective):
+        out = []
+        for o, w in zip(obj.objectives, obj.weights):
+            if isinstance(o, NullObjective):
+                continue
+            if isinstance(o, CompositeObjective):
+                raise ValueError("nested CompositeObjective: `+` flattens them (_objectives.jl:165-176)")
+            out.append((o, w))
+        return out
+    return [(obj, 1.0)]
+
+
+class Evaluator:
+    """Evaluator(prob; eval_hessian=true) -- evaluator.jl:99-288.
+
+    Extra keyword arguments select the device and, for multi-GPU runs, the owned knot range
+    ``k_lo..k_hi`` (1-based, inclusive).  Inputs ``Z`` and ``mu`` are always the GLOBAL vectors;
+    value outputs are the shard-local slabs described by ``shard`` (whole vectors when unsharded)."""
+
+    def __init__(self, prob, eval_hessian=True, device=0, k_lo=0, k_hi=0, verbose=False):
+        self._lib = load_library()
+        self._h = capi.H()
+        traj = prob.trajectory
+        self.trajectory = traj
+        self.eval_hessian = bool(eval_hessian)
+        keep = []  # keep numpy buffers alive across dto_create
+
+        integ = (capi.IntegratorDesc * max(1, len(prob.integrators)))()
+        for i, it in enumerate(prob.integrators):
+            if isinstance(it, BilinearIntegrator):
+                # column-major n x n per generator = transpose of numpy's row-major
+                G = np.ascontiguousarray(np.transpose(it.G, (0, 2, 1)))
+                keep.append(G)
+                integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_BILINEAR, it.x_off, it.x_dim, it.u_off, it.u_dim, _dp(G))
+            elif isinstance(it, DerivativeIntegrator):
+                integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_DERIVATIVE, it.x_off, it.x_dim, it.xdot_off, it.x_dim, None)
+            else:
+                raise NotImplementedError(f"{type(it).__name__} stays on the host (outside the hot-path scope)")
+
+        terms = _flatten_objective(prob.objective)
+        objs = (capi.ObjectiveDesc * max(1, len(terms)))()
+        for i, (o, w) in enumerate(terms):
+            d = capi.ObjectiveDesc()
+            d.weight = w
+            if isinstance(o, MinimumTimeObjective):
+                d.kind, d.D = capi.OBJECTIVE_MINTIME, o.D
+            elif isinstance(o, (QuadraticRegularizer, LinearRegularizer)):
+                d.kind = capi.OBJECTIVE_QUADRATIC if isinstance(o, QuadraticRegularizer) else capi.OBJECTIVE_LINEAR
+                d.comp_off, d.comp_dim = o.comp_off, o.comp_dim
+                R = np.ascontiguousarray(o.R, dtype=np.float64)
+                keep.append(R)
+                d.R = _dp(R)
+                if getattr(o, "baseline", None) is not None:
+                    b = np.ascontiguousarray(o.baseline.T, dtype=np.float64)  # column-major comp_dim x N
+                    keep.append(b)
+                    d.baseline = _dp(b)
+                if o.times is not None:
+                    t = np.ascontiguousarray(o.times, dtype=np.int64)
+                    keep.append(t)
+                    d.times, d.n_times = _ip(t), t.size
+            else:
+                raise NotImplementedError(f"{type(o).__name__} stays on the host (closure-based objective)")
+            objs[i] = d
+
+        nl = [c for c in prob.constraints if isinstance(c, NonlinearKnotPointConstraint)]
+        cons = (capi.ConstraintDesc * max(1, len(nl)))()
+        for i, c in enumerate(nl):
+            comps = np.ascontiguousarray(c.comps, dtype=np.int32)
+            t = np.ascontiguousarray(c.times, dtype=np.int64)
+            keep += [comps, t]
+            cons[i] = capi.ConstraintDesc(NonlinearKnotPointConstraint.KINDS[c.kind], int(c.equality), comps.size, 0,
+                                          comps.ctypes.data_as(capi.c_int32_p), c.c, _ip(t), t.size)
+
+        Z0 = np.ascontiguousarray(traj.vec(), dtype=np.float64)
+        desc = capi.ProblemDesc(capi.DTO_ABI_VERSION, device, traj.N, traj.dim, traj.global_dim,
+                                traj.components[traj.timestep][0], int(eval_hessian), len(prob.integrators),
+                                len(terms), len(nl), 0, integ, objs, cons, _dp(Z0), k_lo, k_hi)
+        if self._lib.dto_create(C.byref(desc), C.byref(self._h)) != 0:
+            raise EngineError(self._lib.dto_last_error(None).decode())
+        v = C.c_int64()
+        self._lib.dto_num_vars(self._h, C.byref(v)); self.n_variables = v.value
+        self._lib.dto_num_cons(self._h, C.byref(v)); self.n_constraints = v.value
+        self._lib.dto_num_dynamics_cons(self._h, C.byref(v)); self.n_dynamics_constraints = v.value
+        self.n_nonlinear_constraints = self.n_constraints - self.n_dynamics_constraints
+        self._lib.dto_jac_nnz(self._h, C.byref(v)); self.n_jacobian_entries = v.value
+        self._lib.dto_hess_nnz(self._h, C.byref(v)); self.n_hessian_entries = v.value
+        self.shard = capi.ShardInfo()
+        self._lib.dto_get_shard_info(self._h, C.byref(self.shard))
+
+    # ---- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self._lib.dto_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dto_destroy(self._h)
+            self._h = capi.H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- MOI surface (host vectors)
+    def initialize(self, features=None):  # MOI.initialize, evaluator.jl:291
+        return None
+
+    def features_available(self):  # evaluator.jl:293-299
+        return ["Grad", "Jac", "Hess"] if self.eval_hessian else ["Grad", "Jac"]
+
+    def _Z(self, Z):
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        if Z.size != self.n_variables:
+            raise ValueError("Z has the wrong length")
+        return Z
+
+    def eval_objective(self, Z):  # evaluator.jl:304
+        Z = self._Z(Z)
+        f = C.c_double()
+        self._check(self._lib.dto_eval_objective(self._h, _dp(Z), C.byref(f)))
+        return f.value
+
+    def eval_objective_gradient(self, grad, Z):  # evaluator.jl:310
+        Z = self._Z(Z)
+        self._check(self._lib.dto_eval_gradient(self._h, _dp(Z), _dp(grad)))
+
+    def eval_constraint(self, g, Z):  # evaluator.jl:323
+        Z = self._Z(Z)
+        self._check(self._lib.dto_eval_constraint(self._h, _dp(Z), _dp(g)))
+
+    def jacobian_structure(self, first=0, count=None):  # evaluator.jl:364 (1-based pairs)
+        count = self.n_jacobian_entries - first if count is None else count
+        r = np.empty(count, dtype=np.int64)
+        c = np.empty(count, dtype=np.int64)
+        self._check(self._lib.dto_jacobian_structure(self._h, first, count, _ip(r), _ip(c)))
+        return r, c
+
+    def eval_constraint_jacobian(self, vals, Z):  # evaluator.jl:368
+        Z = self._Z(Z)
+        self._check(self._lib.dto_eval_jacobian(self._h, _dp(Z), _dp(vals)))
+
+    def hessian_lagrangian_structure(self, first=0, count=None):  # evaluator.jl:385
+        count = self.n_hessian_entries - first if count is None else count
+        r = np.empty(count, dtype=np.int64)
+        c = np.empty(count, dtype=np.int64)
+        self._check(self._lib.dto_hessian_structure(self._h, first, count, _ip(r), _ip(c)))
+        return r, c
+
+    def eval_hessian_lagrangian(self, H, Z, sigma, mu):  # evaluator.jl:389
+        Z = self._Z(Z)
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        self._check(self._lib.dto_eval_hessian(self._h, _dp(Z), float(sigma), _dp(mu), _dp(H)))
+
+    def constraint_bounds(self):  # get_nonlinear_constraints, src/solvers/solve.jl:30-65
+        lo = np.empty(self.n_constraints)
+        hi = np.empty(self.n_constraints)
+        self._check(self._lib.dto_constraint_bounds(self._h, _dp(lo), _dp(hi)))
+        return lo, hi
+
+    def shard_rows(self):
+        n = self.shard.n_row_segments
+        s = np.empty(n, dtype=np.int64)
+        ln = np.empty(n, dtype=np.int64)
+        self._check(self._lib.dto_shard_rows(self._h, _ip(s), _ip(ln)))
+        return s, ln
+
+    # ---- device-resident forms (pointers are integers, e.g. torch.Tensor.data_ptr())
+    def eval_objective_dev(self, dZ, df, stream=0):
+        self._check(self._lib.dto_eval_objective_dev(self._h, dZ, df, stream))
+
+    def eval_gradient_dev(self, dZ, dgrad, stream=0):
+        self._check(self._lib.dto_eval_gradient_dev(self._h, dZ, dgrad, stream))
+
+    def eval_constraint_dev(self, dZ, dg, stream=0):
+        self._check(self._lib.dto_eval_constraint_dev(self._h, dZ, dg, stream))
+
+    def eval_jacobian_dev(self, dZ, dvals, stream=0):
+        self._check(self._lib.dto_eval_jacobian_dev(self._h, dZ, dvals, stream))
+
+    def eval_hessian_dev(self, dZ, sigma, dmu, dvals, stream=0):
+        self._check(self._lib.dto_eval_hessian_dev(self._h, dZ, float(sigma), dmu, dvals, stream))
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        self._check(self._lib.dto_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.dto_profile_reset(self._h))
+
+    def profile_get(self, name):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self._lib.dto_profile_get(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    def last_stats(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self._lib.dto_last_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,158 @@
+"""Host-side mirrors of the reference's hot-path plugin types (same names and argument meaning).
+
+Only the DESCRIPTION lives here; all arithmetic happens in the HIP engine.  Closure-based kinds
+(KnotPointObjective, user g functions, TimeDependentBilinearIntegrator) are outside the hot-path
+scope and raise."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class BilinearIntegrator:
+    """BilinearIntegrator(G, x, u, traj) -- src/integrators/bilinear_integrator.jl:61-85.
+
+    ``G`` is either the reference's closure ``u -> matrix`` (must be affine in u: it is probed at 0
+    and the unit vectors and checked at a random point, because closures cannot cross the C ABI) or
+    an array of shape (m+1, n, n) holding [G(0), G(e_1)-G(0), ...]."""
+
+    def __init__(self, G, x, u, traj):
+        self.x_name, self.u_name = x, u
+        self.x_dim = traj.dims[x]
+        self.u_dim = traj.dims[u]
+        self.var_dim = 2 * self.x_dim + self.u_dim + 1
+        self.dim = self.x_dim * (traj.N - 1)
+        self.x_off = traj.components[x][0]
+        self.u_off = traj.components[u][0]
+        n, m = self.x_dim, self.u_dim
+        if callable(G):
+            G0 = np.asarray(G(np.zeros(m)), dtype=np.float64)
+            drives = [np.asarray(G(np.eye(m)[j]), dtype=np.float64) - G0 for j in range(m)]
+            probe = np.random.default_rng(0).standard_normal(m)
+            want = G0 + sum(probe[j] * drives[j] for j in range(m))
+            got = np.asarray(G(probe), dtype=np.float64)
+            if not np.allclose(got, want, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(want).max())):
+                raise ValueError("BilinearIntegrator: G(u) is not affine in u; only bilinear dynamics run on the device")
+            self.G = np.stack([G0] + drives)
+        else:
+            self.G = np.asarray(G, dtype=np.float64)
+        if self.G.shape != (m + 1, n, n):
+            raise ValueError(f"BilinearIntegrator: generators must have shape {(m + 1, n, n)}")
+
+
+class DerivativeIntegrator:
+    """DerivativeIntegrator(x, xdot, traj) -- src/integrators/derivative_integrator.jl:26-49."""
+
+    def __init__(self, x, xdot, traj):
+        self.x_name, self.xdot_name = x, xdot
+        self.x_dim = traj.dims[x]
+        if traj.dims[xdot] != self.x_dim:
+            raise ValueError("DerivativeIntegrator: x and its derivative must have equal dimension")
+        self.var_dim = 3 * self.x_dim + 1
+        self.dim = self.x_dim * (traj.N - 1)
+        self.x_off = traj.components[x][0]
+        self.xdot_off = traj.components[xdot][0]
+
+
+class AbstractObjective:
+    def __add__(self, other):
+        """`+` flattens nested composites -- src/objectives/_objectives.jl:165-176."""
+        a = self if isinstance(self, CompositeObjective) else CompositeObjective([self], [1.0])
+        b = other if isinstance(other, CompositeObjective) else CompositeObjective([other], [1.0])
+        return CompositeObjective(a.objectives + b.objectives, a.weights + b.weights)
+
+    def __rmul__(self, num):
+        """num * obj -- _objectives.jl:178-187."""
+        if isinstance(self, CompositeObjective):
+            return CompositeObjective(self.objectives, [float(num) * w for w in self.weights])
+        return CompositeObjective([self], [float(num)])
+
+    __mul__ = __rmul__
+
+
+class CompositeObjective(AbstractObjective):
+    """_objectives.jl:106-156."""
+
+    def __init__(self, objectives, weights):
+        self.objectives, self.weights = list(objectives), [float(w) for w in weights]
+
+
+class NullObjective(AbstractObjective):
+    """_objectives.jl:209-230."""
+
+    def __init__(self, traj=None):
+        pass
+
+
+def _times(times, N):
+    if times is None:
+        return None
+    t = np.asarray(list(times), dtype=np.int64)
+    if t.size and (t.min() < 1 or t.max() > N):
+        raise ValueError("times are 1-based knot indices in 1..N")
+    return t
+
+
+class QuadraticRegularizer(AbstractObjective):
+    """QuadraticRegularizer(name, traj, R; baseline, times) -- src/objectives/regularizers.jl:38-64."""
+
+    def __init__(self, name, traj, R, baseline=None, times=None):
+        d = traj.dims[name]
+        self.name = name
+        self.R = np.full(d, float(R)) if np.isscalar(R) else np.asarray(R, dtype=np.float64)
+        if self.R.shape != (d,):
+            raise ValueError("length(R) must equal the component dimension")
+        self.baseline = None if baseline is None else np.asarray(baseline, dtype=np.float64).reshape(d, traj.N)
+        self.times = _times(times, traj.N)
+        self.comp_off, self.comp_dim = traj.components[name][0], d
+
+
+class LinearRegularizer(AbstractObjective):
+    """LinearRegularizer(name, traj, R; times) -- regularizers.jl:207-227."""
+
+    def __init__(self, name, traj, R, times=None):
+        d = traj.dims[name]
+        self.name = name
+        self.R = np.full(d, float(R)) if np.isscalar(R) else np.asarray(R, dtype=np.float64)
+        if self.R.shape != (d,):
+            raise ValueError("length(R) must equal the component dimension")
+        self.times = _times(times, traj.N)
+        self.comp_off, self.comp_dim = traj.components[name][0], d
+
+
+class MinimumTimeObjective(AbstractObjective):
+    """MinimumTimeObjective(traj; D) -- src/objectives/minimum_time_objective.jl:24-40."""
+
+    def __init__(self, traj, D=1.0):
+        self.D = float(D)
+
+
+class NonlinearKnotPointConstraint:
+    """NonlinearKnotPointConstraint(g, names, traj; equality, times) --
+    src/constraints/nonlinear/knot_point_constraint.jl:27-107, restricted to the engine's built-in
+    g kinds: ``"norm"`` (g(v) = [||v|| - c], the shape of test/test_snippets.jl:39-45) and
+    ``"sqnorm"`` (g(v) = [||v||^2 - c])."""
+
+    KINDS = {"norm": 1, "sqnorm": 2}
+
+    def __init__(self, g, names, traj, c=0.0, equality=True, times=None):
+        if callable(g):
+            raise NotImplementedError("closure-based g stays on the host (SURVEY.md §8f rank 2); use a built-in kind")
+        if g not in self.KINDS:
+            raise ValueError(f"unknown built-in g kind {g!r}")
+        names = [names] if isinstance(names, str) else list(names)
+        self.kind, self.var_names, self.c, self.equality = g, names, float(c), bool(equality)
+        self.times = _times(range(1, traj.N + 1) if times is None else times, traj.N)
+        self.comps = np.concatenate([np.asarray(traj.components[n]) for n in names]).astype(np.int32)
+        self.g_dim, self.var_dim = 1, self.comps.size
+        self.dim = self.g_dim * self.times.size
+
+
+class DirectTrajOptProblem:
+    """DirectTrajOptProblem(traj, obj, integrators; constraints) -- src/problems.jl:50-122 (fields only;
+    the linear-constraint extraction done there is solver set-up, outside the hot path)."""
+
+    def __init__(self, trajectory, objective, integrators, constraints=()):
+        self.trajectory = trajectory
+        self.objective = objective
+        self.integrators = [integrators] if not isinstance(integrators, (list, tuple)) else list(integrators)
+        self.constraints = list(constraints)

@@ -1,0 +1,171 @@
+/*
+ * dto_engine.h -- C ABI of the MI355X-native NLP-callback engine for DirectTrajOpt.jl.
+ *
+ * Drop-in boundary: the seven MOI.AbstractNLPEvaluator methods implemented by the reference's
+ * `Evaluator` (src/solvers/evaluator.jl:66-98, 291-456).  A Julia shim `GPUEvaluator <:
+ * MOI.AbstractNLPEvaluator` forwards each MOI method to one entry point below through `@ccall`
+ * (see INTEGRATION.md).  Plain C: pointers + sizes only, no exceptions cross the boundary.
+ *
+ * Conventions
+ *   - All floating-point data are IEEE double; all index outputs are int64, 1-BASED (Julia/MOI).
+ *   - Matrices are dense COLUMN-MAJOR (Julia's native layout).
+ *   - The NLP variable vector is Z = [datavec; global_data], datavec knot-major
+ *     (src/solvers/evaluator.jl:230, 474-482); component offsets are 0-based inside a knot.
+ *   - Return value 0 = OK, non-zero = error; text via dto_last_error().
+ *   - One in-flight call per handle (solvers call back serially).
+ *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (passed as void*); they enqueue
+ *     work and return without synchronising.  The plain entry points take HOST pointers, copy in/out
+ *     and block until the result is in the caller's buffer.
+ *   - A handle may own a SHARD of the knot range [k_lo, k_hi] (1-based, inclusive).  All value
+ *     outputs are then the shard-local contiguous slabs described by dto_shard_info; with
+ *     k_lo = 1, k_hi = N the slabs are the whole vectors.
+ */
+#ifndef DTO_ENGINE_H
+#define DTO_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTO_ABI_VERSION 1
+
+/* integrator kinds (src/integrators/) */
+#define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
+#define DTO_INTEGRATOR_DERIVATIVE 2 /* derivative_integrator.jl:26-49 */
+
+/* objective term kinds (src/objectives/) */
+#define DTO_OBJECTIVE_QUADRATIC_REGULARIZER 1 /* regularizers.jl:38-167   */
+#define DTO_OBJECTIVE_LINEAR_REGULARIZER 2    /* regularizers.jl:207-313  */
+#define DTO_OBJECTIVE_MINIMUM_TIME 3          /* minimum_time_objective.jl:24-76 */
+
+/* built-in g kinds for NonlinearKnotPointConstraint (knot_point_constraint.jl:27-107) */
+#define DTO_CONSTRAINT_NORM_MINUS_C 1   /* g(v) = [ ||v||_2   - c ] */
+#define DTO_CONSTRAINT_SQNORM_MINUS_C 2 /* g(v) = [ ||v||_2^2 - c ] */
+
+typedef struct dto_integrator_desc {
+    int32_t kind;
+    int32_t x_off;  /* state component offset inside a knot (0-based) */
+    int32_t x_dim;
+    int32_t u_off;  /* bilinear: control offset; derivative: offset of the derivative component */
+    int32_t u_dim;  /* bilinear: number of drives m; derivative: ignored (= x_dim) */
+    const double* G; /* bilinear: (m+1) matrices x_dim*x_dim, column-major, G[0] = G(0) (drift),
+                        G[j] = G(e_j) - G(0) (drive j); copied at create.  NULL for derivative. */
+} dto_integrator_desc;
+
+typedef struct dto_objective_desc {
+    int32_t kind;
+    int32_t comp_off;
+    int32_t comp_dim;
+    int32_t reserved;
+    double weight;          /* CompositeObjective weight (_objectives.jl:106-156) */
+    double D;               /* MinimumTimeObjective scale */
+    const double* R;        /* comp_dim weights (regularizers) */
+    const double* baseline; /* comp_dim x N column-major, or NULL = zeros (QuadraticRegularizer) */
+    const int64_t* times;   /* 1-based knot indices, or NULL = 1:N */
+    int64_t n_times;
+} dto_objective_desc;
+
+typedef struct dto_constraint_desc {
+    int32_t kind;
+    int32_t equality;       /* 1: g = 0, 0: g <= 0 (src/solvers/solve.jl:54-62) */
+    int32_t n_comps;
+    int32_t reserved;
+    const int32_t* comps;   /* knot-local component indices (0-based), vcat of var_names comps */
+    double c;
+    const int64_t* times;   /* 1-based knot indices (required) */
+    int64_t n_times;
+} dto_constraint_desc;
+
+typedef struct dto_problem_desc {
+    int32_t abi_version;    /* DTO_ABI_VERSION */
+    int32_t device;         /* HIP device ordinal */
+    int64_t N;              /* knots */
+    int32_t z;              /* traj.dim: components per knot */
+    int32_t gd;             /* traj.global_dim */
+    int32_t dt_idx;         /* component index of the timestep inside a knot (0-based); the engine
+                               requires a timestep COMPONENT (bilinear_integrator.jl:123) */
+    int32_t eval_hessian;   /* Evaluator(...; eval_hessian) -> features_available (evaluator.jl:293) */
+    int32_t n_integrators;
+    int32_t n_objectives;
+    int32_t n_constraints;
+    int32_t reserved;
+    const dto_integrator_desc* integrators;
+    const dto_objective_desc* objectives;
+    const dto_constraint_desc* constraints;
+    const double* Z0;       /* initial point, length z*N+gd: constraint sparsity patterns are taken
+                               from the numeric Jacobian at Z0 (evaluator.jl:136) */
+    int64_t k_lo, k_hi;     /* owned knot range, 1-based inclusive; 0,0 = whole trajectory */
+} dto_problem_desc;
+
+typedef struct dto_handle dto_handle;
+
+typedef struct dto_shard_info {
+    int64_t k_lo, k_hi;
+    int64_t n_vars, n_cons, jac_nnz, hess_nnz;     /* GLOBAL sizes */
+    int64_t grad_lo, grad_len;                      /* gradient slab: entries of owned knots */
+    int64_t jac_lo, jac_len;                        /* Jacobian value slab (CSC order)        */
+    int64_t hess_lo, hess_len;                      /* Hessian value slab (upper-tri CSC order) */
+    int64_t cons_len;                               /* local constraint rows (see dto_shard_rows) */
+    int32_t n_row_segments;
+    int32_t reserved;
+} dto_shard_info;
+
+/* lifecycle -- replaces Evaluator(prob; eval_hessian) at ipopt_solver/solver.jl:68-69 and
+ * ext/MadNLPSolverExt/solver.jl:81 */
+int dto_create(const dto_problem_desc* desc, dto_handle** out);
+void dto_destroy(dto_handle* h);
+const char* dto_last_error(const dto_handle* h); /* h may be NULL: error of the last failed create */
+
+/* sizes: Evaluator fields n_constraints / n_dynamics_constraints / n_nonlinear_constraints
+ * (evaluator.jl:73-76) and structure lengths */
+int dto_num_vars(const dto_handle* h, int64_t* out);
+int dto_num_cons(const dto_handle* h, int64_t* out);
+int dto_num_dynamics_cons(const dto_handle* h, int64_t* out);
+int dto_jac_nnz(const dto_handle* h, int64_t* out);
+int dto_hess_nnz(const dto_handle* h, int64_t* out);
+int dto_features_available(const dto_handle* h, int32_t* grad, int32_t* jac, int32_t* hess); /* evaluator.jl:293-299 */
+int dto_get_shard_info(const dto_handle* h, dto_shard_info* out);
+/* local constraint buffer = concatenation of global row segments [start1 (1-based), len] */
+int dto_shard_rows(const dto_handle* h, int64_t* start1, int64_t* len);
+
+/* structure -- MOI.jacobian_structure (evaluator.jl:364) / MOI.hessian_lagrangian_structure (:385).
+ * Writes entries [first, first+count) (0-based position in the GLOBAL CSC order), 1-based pairs. */
+int dto_jacobian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols);
+int dto_hessian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols);
+/* row bounds handed to the solver, src/solvers/solve.jl:30-65: lower/upper per NLP row */
+int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper);
+
+/* host-pointer callbacks (blocking) */
+int dto_eval_objective(dto_handle* h, const double* Z, double* f);                 /* evaluator.jl:304 */
+int dto_eval_gradient(dto_handle* h, const double* Z, double* grad);               /* evaluator.jl:310 */
+int dto_eval_constraint(dto_handle* h, const double* Z, double* g);                /* evaluator.jl:323 */
+int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals);               /* evaluator.jl:368 */
+int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double* mu,
+                     double* vals);                                                /* evaluator.jl:389 */
+/* y = J w  /  y = J' w without materialising J on the host (evaluator.jl:406-456) */
+int dto_eval_jacobian_product(dto_handle* h, const double* Z, const double* w, double* y);
+int dto_eval_jacobian_transpose_product(dto_handle* h, const double* Z, const double* w, double* y);
+
+/* device-pointer callbacks (asynchronous on `stream`; outputs stay in HBM) */
+int dto_eval_objective_dev(dto_handle* h, const double* dZ, double* df, void* stream);
+int dto_eval_gradient_dev(dto_handle* h, const double* dZ, double* dgrad, void* stream);
+int dto_eval_constraint_dev(dto_handle* h, const double* dZ, double* dg, void* stream);
+int dto_eval_jacobian_dev(dto_handle* h, const double* dZ, double* dvals, void* stream);
+int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const double* dmu,
+                         double* dvals, void* stream);
+
+/* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */
+int dto_profile_enable(dto_handle* h, int32_t on);
+int dto_profile_reset(dto_handle* h);
+/* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain), "expmv" (tangent step), "all".
+ * Returns accumulated device milliseconds, launches and algorithmic FLOPs of those launches. */
+int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops);
+/* diagnostics of the last Jacobian call: max squarings used, Taylor terms used by the tangent sweep */
+int dto_last_stats(const dto_handle* h, int32_t* max_squarings, int32_t* expmv_terms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTO_ENGINE_H */

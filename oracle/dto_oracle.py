@@ -1,0 +1,726 @@
+"""CPU oracle for the DirectTrajOpt.jl NLP-callback hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a NumPy/SciPy *restatement* of the reference's evaluator path.  It is the checker
+used by ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg; nothing in
+the product path (``directtrajopt.jl_amd/``) may import it.
+
+Parity status: **values unpinned against the Julia reference** (no ``julia`` in the build
+container, and the reference's own tests hold no literal expected values for this path, see
+SURVEY.md §4/§8c).  The oracle is instead pinned by
+  * the reference's structure-construction rules, re-enacted literally with scipy.sparse
+    (pattern matrices -> vstack -> CSC walk), so the sparsity indices follow
+    ``src/solvers/evaluator.jl:119-209`` by construction;
+  * the one hard-coded trajectory of the reference's tests (``test/test_utils.jl:57-82``) with the
+    closed-form ``DerivativeIntegrator`` answers (``tests/test_oracle_pinning.py``);
+  * complex-step / high-precision (mpmath) differentiation of ``x_{k+1} - exp(dt G(u)) x_k`` for
+    the bilinear first- and second-order terms (same test file).
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+Indices at this API are 0-based unless a name ends in ``1`` (1-based, Julia/MOI convention).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+# ----------------------------------------------------------------------------------------------
+# Problem description (mirrors include/dto_engine.h)
+# ----------------------------------------------------------------------------------------------
+
+
+@dataclass
+class BilinearIntegrator:
+    """x_{k+1} - exp(dt_k G(u_k)) x_k = 0, G(u) = G[0] + sum_j u_j G[j].
+
+    src/integrators/bilinear_integrator.jl:61-85 (defect at :81)."""
+
+    x_off: int
+    x_dim: int
+    u_off: int
+    u_dim: int
+    G: np.ndarray  # (u_dim+1, n, n): drift then drives
+
+    kind = "bilinear"
+
+
+@dataclass
+class DerivativeIntegrator:
+    """x_{k+1} - x_k - dt_k xdot_k = 0.  src/integrators/derivative_integrator.jl:26-49 (:45)."""
+
+    x_off: int
+    x_dim: int
+    xdot_off: int
+
+    kind = "derivative"
+
+
+@dataclass
+class QuadraticRegularizer:
+    """src/objectives/regularizers.jl:38-167."""
+
+    comp_off: int
+    comp_dim: int
+    R: np.ndarray
+    baseline: Optional[np.ndarray] = None  # (comp_dim, N) or None (= zeros)
+    times1: Optional[Sequence[int]] = None  # 1-based knots, None = 1:N
+
+    kind = "quadratic"
+
+
+@dataclass
+class LinearRegularizer:
+    """src/objectives/regularizers.jl:207-313."""
+
+    comp_off: int
+    comp_dim: int
+    R: np.ndarray
+    times1: Optional[Sequence[int]] = None
+
+    kind = "linear"
+
+
+@dataclass
+class MinimumTimeObjective:
+    """src/objectives/minimum_time_objective.jl:24-76."""
+
+    D: float = 1.0
+
+    kind = "mintime"
+
+
+@dataclass
+class KnotConstraint:
+    """NonlinearKnotPointConstraint with a built-in g (closed set).
+
+    kind "norm":   g(v) = [ ||v||_2 - c ]      (shape of test/test_snippets.jl:39-45)
+    kind "sqnorm": g(v) = [ ||v||_2^2 - c ]
+    src/constraints/nonlinear/knot_point_constraint.jl:27-107, 235-294."""
+
+    kind: str
+    comps: Sequence[int]  # 0-based knot-local component indices (vcat of var_names comps)
+    c: float
+    times1: Sequence[int]
+    equality: bool = False
+
+    g_dim = 1
+
+
+@dataclass
+class Problem:
+    N: int
+    z: int  # traj.dim
+    dt_idx: int  # 0-based component index of the timestep inside a knot
+    integrators: List[object]
+    objectives: List[object] = field(default_factory=list)  # terms
+    weights: Optional[List[float]] = None  # composite weights (None: all 1)
+    constraints: List[KnotConstraint] = field(default_factory=list)
+    gd: int = 0  # global_dim (columns exist, no hot-path term touches them)
+    Z0: Optional[np.ndarray] = None  # initial point (value-dependent constraint patterns)
+
+    @property
+    def K(self):
+        return self.N - 1
+
+    @property
+    def n_vars(self):
+        return self.z * self.N + self.gd
+
+    def w(self, i):
+        return 1.0 if self.weights is None else float(self.weights[i])
+
+
+def times0(term_times1, N):
+    if term_times1 is None:
+        return np.arange(N)
+    return np.asarray(term_times1, dtype=np.int64) - 1
+
+
+# ----------------------------------------------------------------------------------------------
+# Integrators
+# ----------------------------------------------------------------------------------------------
+
+
+def _knot(Z, prob, k0):
+    return Z[k0 * prob.z:(k0 + 1) * prob.z]
+
+
+def _Gu(integ, u):
+    return integ.G[0] + np.tensordot(u, integ.G[1:], axes=(0, 0))
+
+
+def integrator_evaluate(integ, prob, Z):
+    """evaluate! -- bilinear_integrator.jl:98-107, derivative_integrator.jl:55-64."""
+    d = integ.x_dim
+    out = np.zeros(d * prob.K)
+    for k in range(prob.K):
+        zk, zk1 = _knot(Z, prob, k), _knot(Z, prob, k + 1)
+        dt = zk[prob.dt_idx]
+        xk = zk[integ.x_off:integ.x_off + d]
+        xk1 = zk1[integ.x_off:integ.x_off + d]
+        if integ.kind == "bilinear":
+            u = zk[integ.u_off:integ.u_off + integ.u_dim]
+            out[k * d:(k + 1) * d] = xk1 - sla.expm(dt * _Gu(integ, u)) @ xk
+        else:
+            xd = zk[integ.xdot_off:integ.xdot_off + d]
+            out[k * d:(k + 1) * d] = xk1 - xk - dt * xd
+    return out
+
+
+def integrator_jacobian_structure(integ, prob):
+    """get_jacobian_structure -- src/integrators/_integrators.jl:49-60."""
+    d, z = integ.x_dim, prob.z
+    S = sp.lil_matrix((d * prob.K, prob.n_vars))
+    for k in range(prob.K):
+        S[k * d:(k + 1) * d, k * z:(k + 2) * z] = 1.0
+    return S.tocsc()
+
+
+def bilinear_block_jacobian(integ, prob, zk):
+    """Dense n x z block d(delta_k)/d(z_k) of the bilinear defect (the x_{k+1} half is +I).
+
+    Exact derivative of bilinear_integrator.jl:81 (the reference differentiates the same expression
+    with ForwardDiff at :111-131)."""
+    n, m, z = integ.x_dim, integ.u_dim, prob.z
+    dt = zk[prob.dt_idx]
+    x = zk[integ.x_off:integ.x_off + n]
+    u = zk[integ.u_off:integ.u_off + m]
+    Gu = _Gu(integ, u)
+    A = dt * Gu
+    E = sla.expm(A)
+    B = np.zeros((n, z))
+    B[:, integ.x_off:integ.x_off + n] += -E
+    for j in range(m):
+        L = sla.expm_frechet(A, dt * integ.G[1 + j], compute_expm=False)
+        B[:, integ.u_off + j] += -(L @ x)
+    B[:, prob.dt_idx] += -(Gu @ (E @ x))
+    return B
+
+
+def integrator_jacobian(integ, prob, Z):
+    """eval_jacobian -- bilinear_integrator.jl:111-131, derivative_integrator.jl:68-86.
+
+    Returned as CSC with exact zeros NOT stored (Julia's sparse setindex! drops zeros written to
+    unstored positions, which is how the ForwardDiff.jacobian! into a sparse view behaves)."""
+    d, z = integ.x_dim, prob.z
+    J = sp.lil_matrix((d * prob.K, prob.n_vars))
+    for k in range(prob.K):
+        zk = _knot(Z, prob, k)
+        blk = np.zeros((d, 2 * z))
+        if integ.kind == "bilinear":
+            blk[:, :z] = bilinear_block_jacobian(integ, prob, zk)
+        else:
+            dt = zk[prob.dt_idx]
+            xd = zk[integ.xdot_off:integ.xdot_off + d]
+            blk[:, integ.x_off:integ.x_off + d] += -np.eye(d)
+            blk[:, integ.xdot_off:integ.xdot_off + d] += -dt * np.eye(d)
+            blk[:, prob.dt_idx] += -xd
+        blk[:, z + integ.x_off:z + integ.x_off + d] += np.eye(d)
+        J[k * d:(k + 1) * d, k * z:(k + 2) * z] = blk
+    J = J.tocsc()
+    J.eliminate_zeros()
+    return J
+
+
+def integrator_hessian_structure(prob):
+    """get_hessian_of_lagrangian_structure -- src/integrators/_integrators.jl:68-77."""
+    z = prob.z
+    S = sp.lil_matrix((prob.n_vars, prob.n_vars))
+    for k in range(prob.K):
+        S[k * z:(k + 2) * z, k * z:(k + 2) * z] = 1.0
+    return S.tocsc()
+
+
+def _second_frechet_action(A, E1, E2, x):
+    """d^2/(ds dt) exp(A + s E1 + t E2) x at 0, via the 3x3 block-triangular exponential."""
+    n = A.shape[0]
+    Zr = np.zeros((n, n))
+
+    def top_right(Ea, Eb):
+        M = np.block([[A, Ea, Zr], [Zr, A, Eb], [Zr, Zr, A]])
+        return sla.expm(M)[:n, 2 * n:]
+
+    return (top_right(E1, E2) + top_right(E2, E1)) @ x
+
+
+def bilinear_block_hessian(integ, prob, zk, mu):
+    """Dense z x z Hessian of mu' f wrt z_k for the bilinear defect (x_{k+1} rows/cols are 0).
+
+    Exact second derivative of bilinear_integrator.jl:81 (reference: ForwardDiff.hessian,
+    :135-161)."""
+    n, m, z = integ.x_dim, integ.u_dim, prob.z
+    dt = zk[prob.dt_idx]
+    x = zk[integ.x_off:integ.x_off + n]
+    u = zk[integ.u_off:integ.u_off + m]
+    Gu = _Gu(integ, u)
+    A = dt * Gu
+    E = sla.expm(A)
+    H = np.zeros((z, z))
+    xs = slice(integ.x_off, integ.x_off + n)
+    Ls = [sla.expm_frechet(A, dt * integ.G[1 + j], compute_expm=False) for j in range(m)]
+    Ex = E @ x
+    for j in range(m):
+        uj = integ.u_off + j
+        v = -(Ls[j].T @ mu)
+        H[xs, uj] += v
+        H[uj, xs] += v
+        # d/d(dt) d/du_j [exp(dt G) x] = G_j E x + G L(A, dt G_j) x
+        val = -(mu @ (integ.G[1 + j] @ Ex + Gu @ (Ls[j] @ x)))
+        H[uj, prob.dt_idx] += val
+        H[prob.dt_idx, uj] += val
+        for i in range(j + 1):
+            ui = integ.u_off + i
+            val = -(mu @ _second_frechet_action(A, dt * integ.G[1 + i], dt * integ.G[1 + j], x))
+            H[ui, uj] += val
+            if i != j:
+                H[uj, ui] += val
+    v = -((Gu @ E).T @ mu)
+    H[xs, prob.dt_idx] += v
+    H[prob.dt_idx, xs] += v
+    H[prob.dt_idx, prob.dt_idx] += -(mu @ (Gu @ (Gu @ Ex)))
+    return H
+
+
+def integrator_hessian(integ, prob, Z, mu):
+    """eval_hessian_of_lagrangian -- bilinear_integrator.jl:135-161, derivative_integrator.jl:90-116."""
+    d, z = integ.x_dim, prob.z
+    H = sp.lil_matrix((prob.n_vars, prob.n_vars))
+    for k in range(prob.K):
+        zk = _knot(Z, prob, k)
+        muk = mu[k * d:(k + 1) * d]
+        blk = np.zeros((2 * z, 2 * z))
+        if integ.kind == "bilinear":
+            blk[:z, :z] = bilinear_block_hessian(integ, prob, zk, muk)
+        else:
+            for i in range(d):
+                blk[integ.xdot_off + i, prob.dt_idx] += -muk[i]
+                blk[prob.dt_idx, integ.xdot_off + i] += -muk[i]
+        cur = H[k * z:(k + 2) * z, k * z:(k + 2) * z].toarray()
+        H[k * z:(k + 2) * z, k * z:(k + 2) * z] = cur + blk  # `.+=` at :158
+    return H.tocsc()
+
+
+# ----------------------------------------------------------------------------------------------
+# Nonlinear knot-point constraints (built-in g kinds)
+# ----------------------------------------------------------------------------------------------
+
+
+def _g(con, v):
+    if con.kind == "norm":
+        return np.array([np.sqrt(v @ v) - con.c])
+    if con.kind == "sqnorm":
+        return np.array([v @ v - con.c])
+    raise ValueError(con.kind)
+
+
+def _g_jac(con, v):
+    if con.kind == "norm":
+        return (v / np.sqrt(v @ v))[None, :]
+    return (2.0 * v)[None, :]
+
+
+def _g_hess(con, v, mu):
+    d = len(v)
+    if con.kind == "norm":
+        r = np.sqrt(v @ v)
+        return mu[0] * (np.eye(d) / r - np.outer(v, v) / r**3)
+    return mu[0] * 2.0 * np.eye(d)
+
+
+def constraint_evaluate(con, prob, Z):
+    """evaluate! -- knot_point_constraint.jl:235-247."""
+    out = np.zeros(con.g_dim * len(con.times1))
+    comps = np.asarray(con.comps)
+    for i, t1 in enumerate(con.times1):
+        v = _knot(Z, prob, t1 - 1)[comps]
+        out[i * con.g_dim:(i + 1) * con.g_dim] = _g(con, v)
+    return out
+
+
+def constraint_jacobian(con, prob, Z):
+    """eval_jacobian -- knot_point_constraint.jl:254-268 (exact zeros not stored)."""
+    J = sp.lil_matrix((con.g_dim * len(con.times1), prob.n_vars))
+    comps = np.asarray(con.comps)
+    for i, t1 in enumerate(con.times1):
+        v = _knot(Z, prob, t1 - 1)[comps]
+        Jg = _g_jac(con, v)
+        for r in range(con.g_dim):
+            for c, comp in enumerate(comps):
+                if Jg[r, c] != 0.0:
+                    J[i * con.g_dim + r, (t1 - 1) * prob.z + comp] = Jg[r, c]
+    return J.tocsc()
+
+
+def constraint_hessian(con, prob, Z, mu):
+    """eval_hessian_of_lagrangian -- knot_point_constraint.jl:275-294."""
+    H = sp.lil_matrix((prob.n_vars, prob.n_vars))
+    comps = np.asarray(con.comps)
+    for i, t1 in enumerate(con.times1):
+        v = _knot(Z, prob, t1 - 1)[comps]
+        Hg = _g_hess(con, v, mu[i * con.g_dim:(i + 1) * con.g_dim])
+        base = (t1 - 1) * prob.z
+        for a, ca in enumerate(comps):
+            for b, cb in enumerate(comps):
+                if Hg[a, b] != 0.0:
+                    H[base + ca, base + cb] = Hg[a, b]
+    return H.tocsc()
+
+
+# ----------------------------------------------------------------------------------------------
+# Objectives
+# ----------------------------------------------------------------------------------------------
+
+
+def _baseline(term, t0):
+    if term.baseline is None:
+        return np.zeros(term.comp_dim)
+    return np.asarray(term.baseline)[:, t0]
+
+
+def term_value(term, prob, Z):
+    """objective_value -- regularizers.jl:79-91, :240-249, minimum_time_objective.jl:44-50."""
+    J = 0.0
+    if term.kind == "mintime":
+        for k in range(prob.K):
+            J += _knot(Z, prob, k)[prob.dt_idx]
+        return term.D * J
+    for t0 in times0(term.times1, prob.N):
+        zk = _knot(Z, prob, t0)
+        v = zk[term.comp_off:term.comp_off + term.comp_dim]
+        dt = zk[prob.dt_idx]
+        if term.kind == "quadratic":
+            r = dt * (v - _baseline(term, t0))
+            J += 0.5 * r @ (term.R * r)
+        else:
+            J += dt * (term.R @ v)
+    return J
+
+
+def term_gradient_accumulate(grad, term, prob, Z, scale=1.0):
+    """gradient! (accumulating form) -- regularizers.jl:93-115, :251-271, minimum_time_objective.jl:52-66."""
+    if term.kind == "mintime":
+        for k in range(prob.K):
+            grad[k * prob.z + prob.dt_idx] += scale * term.D
+        return
+    for t0 in times0(term.times1, prob.N):
+        zk = _knot(Z, prob, t0)
+        v = zk[term.comp_off:term.comp_off + term.comp_dim]
+        dt = zk[prob.dt_idx]
+        base = t0 * prob.z
+        if term.kind == "quadratic":
+            dv = v - _baseline(term, t0)
+            grad[base + term.comp_off:base + term.comp_off + term.comp_dim] += scale * dt**2 * (term.R * dv)
+            grad[base + prob.dt_idx] += scale * (dv @ (term.R * dv)) * dt
+        else:
+            grad[base + term.comp_off:base + term.comp_off + term.comp_dim] += scale * term.R * dt
+            grad[base + prob.dt_idx] += scale * (term.R @ v)
+
+
+def term_hessian_structure(term, prob):
+    """hessian_structure -- regularizers.jl:117-140, :273-293, minimum_time_objective.jl:68-72."""
+    S = sp.lil_matrix((prob.n_vars, prob.n_vars))
+    if term.kind == "mintime":
+        return S.tocsc()
+    for t0 in times0(term.times1, prob.N):
+        base = t0 * prob.z
+        vs = slice(base + term.comp_off, base + term.comp_off + term.comp_dim)
+        di = base + prob.dt_idx
+        if term.kind == "quadratic":
+            S[vs, vs] = 1.0
+            S[vs, di] = 1.0
+            S[di, di] = 1.0
+        else:
+            S[vs, di] = 1.0
+    return S.tocsc()
+
+
+def term_full_hessian(term, prob, Z):
+    """get_full_hessian -- regularizers.jl:142-167, :295-313 (setindex! order matters: the
+    (v,dt) block and the (dt,dt) entry are written after the (v,v) block and overwrite it when the
+    timestep is itself inside `v`; not the case for any hot-path configuration)."""
+    H = sp.lil_matrix((prob.n_vars, prob.n_vars))
+    if term.kind == "mintime":
+        return H.tocsc()
+    for t0 in times0(term.times1, prob.N):
+        zk = _knot(Z, prob, t0)
+        dt = zk[prob.dt_idx]
+        base = t0 * prob.z
+        vi = np.arange(base + term.comp_off, base + term.comp_off + term.comp_dim)
+        di = base + prob.dt_idx
+        v = zk[term.comp_off:term.comp_off + term.comp_dim]
+        if term.kind == "quadratic":
+            r = v - _baseline(term, t0)
+            for a in range(term.comp_dim):
+                H[vi[a], vi[a]] = dt**2 * term.R[a]
+            for a in range(term.comp_dim):
+                H[vi[a], di] = 2 * dt * term.R[a] * r[a]
+            H[di, di] = r @ (term.R * r)
+        else:
+            for a in range(term.comp_dim):
+                H[vi[a], di] = term.R[a]
+    return H.tocsc()
+
+
+def objective_value(prob, Z):
+    """CompositeObjective -- src/objectives/_objectives.jl:111-117."""
+    return sum(prob.w(i) * term_value(t, prob, Z) for i, t in enumerate(prob.objectives))
+
+
+def objective_gradient(prob, Z):
+    """CompositeObjective gradient! -- _objectives.jl:119-128 (engine convention: zero-filled
+    first)."""
+    g = np.zeros(prob.n_vars)
+    for i, t in enumerate(prob.objectives):
+        term_gradient_accumulate(g, t, prob, Z, scale=prob.w(i))
+    return g
+
+
+def objective_full_hessian(prob, Z):
+    """CompositeObjective get_full_hessian -- _objectives.jl:149-156."""
+    H = sp.csc_matrix((prob.n_vars, prob.n_vars))
+    for i, t in enumerate(prob.objectives):
+        H = H + prob.w(i) * term_full_hessian(t, prob, Z)
+    return H.tocsc()
+
+
+# ----------------------------------------------------------------------------------------------
+# Evaluator (MOI.AbstractNLPEvaluator surface) -- src/solvers/evaluator.jl
+# ----------------------------------------------------------------------------------------------
+
+
+def _findnz_colmajor(M):
+    """(rows, cols) of stored entries in CSC order = Julia's findnz order."""
+    M = M.tocsc()
+    M.sort_indices()
+    cols = np.repeat(np.arange(M.shape[1]), np.diff(M.indptr))
+    return M.indices.astype(np.int64), cols.astype(np.int64)
+
+
+class OracleEvaluator:
+    """Restates `Evaluator` (evaluator.jl:66-288) and its MOI methods (:291-456, :474-647)."""
+
+    def __init__(self, prob: Problem, eval_hessian: bool = True):
+        self.prob = prob
+        self.eval_hessian = eval_hessian
+        Z0 = np.asarray(prob.Z0, dtype=np.float64)
+        self.n_dynamics_constraints = sum(i.x_dim * prob.K for i in prob.integrators)
+        self.n_nonlinear_constraints = sum(c.g_dim * len(c.times1) for c in prob.constraints)
+        self.n_constraints = self.n_dynamics_constraints + self.n_nonlinear_constraints
+
+        # Jacobian structure, evaluator.jl:119-149
+        blocks = [integrator_jacobian_structure(i, prob) for i in prob.integrators]
+        blocks += [constraint_jacobian(c, prob, Z0) for c in prob.constraints]
+        if blocks:
+            dg = sp.vstack(blocks, format="csc")
+        else:
+            dg = sp.csc_matrix((0, prob.n_vars))
+        self.jac_rows, self.jac_cols = _findnz_colmajor(dg)
+
+        # Hessian structure, evaluator.jl:151-209
+        H = sp.csc_matrix((prob.n_vars, prob.n_vars))
+        for _ in prob.integrators:
+            H = H + integrator_hessian_structure(prob)
+        for c in prob.constraints:
+            H = H + abs(constraint_hessian(c, prob, Z0, np.ones(c.g_dim * len(c.times1))))
+        for t in prob.objectives:
+            H = H + term_hessian_structure(t, prob)
+        r, c = _findnz_colmajor(H)
+        keep = r <= c
+        self.hess_rows, self.hess_cols = r[keep], c[keep]
+
+        # offsets, evaluator.jl:211-227
+        self.integrator_offsets = np.concatenate(
+            [[0], np.cumsum([i.x_dim * prob.K for i in prob.integrators])]).astype(np.int64)
+        self.constraint_offsets = (self.n_dynamics_constraints + np.concatenate(
+            [[0], np.cumsum([c.g_dim * len(c.times1) for c in prob.constraints])])).astype(np.int64)
+
+        self._jmap = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(self.jac_rows, self.jac_cols))}
+        self._hmap = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(self.hess_rows, self.hess_cols))}
+
+    # MOI.jacobian_structure / hessian_lagrangian_structure (1-based tuples), evaluator.jl:364,385
+    def jacobian_structure1(self):
+        return self.jac_rows + 1, self.jac_cols + 1
+
+    def hessian_structure1(self):
+        return self.hess_rows + 1, self.hess_cols + 1
+
+    def eval_objective(self, Z):
+        return objective_value(self.prob, Z)  # evaluator.jl:304-308
+
+    def eval_objective_gradient(self, Z):
+        return objective_gradient(self.prob, Z)  # evaluator.jl:310-318
+
+    def eval_constraint(self, Z):
+        """evaluator.jl:323-362."""
+        g = np.zeros(self.n_constraints)
+        for i, integ in enumerate(self.prob.integrators):
+            o = self.integrator_offsets[i]
+            g[o:o + integ.x_dim * self.prob.K] = integrator_evaluate(integ, self.prob, Z)
+        for i, con in enumerate(self.prob.constraints):
+            o = self.constraint_offsets[i]
+            g[o:o + con.g_dim * len(con.times1)] = constraint_evaluate(con, self.prob, Z)
+        return g
+
+    def eval_constraint_jacobian(self, Z):
+        """_fill_jacobian_values! -- evaluator.jl:491-551 (assignment, unknown positions dropped)."""
+        out = np.zeros(len(self.jac_rows))
+        comps = [(self.integrator_offsets[i], integrator_jacobian(integ, self.prob, Z))
+                 for i, integ in enumerate(self.prob.integrators)]
+        comps += [(self.constraint_offsets[i], constraint_jacobian(con, self.prob, Z))
+                  for i, con in enumerate(self.prob.constraints)]
+        for off, M in comps:
+            r, c = _findnz_colmajor(M)
+            M = M.tocsc()
+            M.sort_indices()
+            for rr, cc, vv in zip(r, c, M.data):
+                idx = self._jmap.get((int(off + rr), int(cc)))
+                if idx is not None:
+                    out[idx] = vv
+        return out
+
+    def eval_hessian_lagrangian(self, Z, sigma, mu):
+        """_fill_hessian_values! -- evaluator.jl:560-647 (accumulation, upper triangle only)."""
+        out = np.zeros(len(self.hess_rows))
+
+        def scatter(M, scale=1.0):
+            r, c = _findnz_colmajor(M)
+            M = M.tocsc()
+            M.sort_indices()
+            for rr, cc, vv in zip(r, c, M.data):
+                if rr <= cc:
+                    idx = self._hmap.get((int(rr), int(cc)))
+                    if idx is not None:
+                        out[idx] += scale * vv
+
+        for i, integ in enumerate(self.prob.integrators):
+            o = self.integrator_offsets[i]
+            scatter(integrator_hessian(integ, self.prob, Z, mu[o:o + integ.x_dim * self.prob.K]))
+        for i, con in enumerate(self.prob.constraints):
+            o = self.constraint_offsets[i]
+            scatter(constraint_hessian(con, self.prob, Z, mu[o:o + con.g_dim * len(con.times1)]))
+        if sigma != 0:
+            scatter(objective_full_hessian(self.prob, Z), sigma)
+        return out
+
+    def row_bounds(self):
+        """get_nonlinear_constraints -- src/solvers/solve.jl:30-65."""
+        lo = np.zeros(self.n_constraints)
+        hi = np.zeros(self.n_constraints)
+        for i, con in enumerate(self.prob.constraints):
+            if not con.equality:
+                o = self.constraint_offsets[i]
+                lo[o:o + con.g_dim * len(con.times1)] = -np.inf
+        return lo, hi
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic problem generators (own counter-based RNG: Julia's Xoshiro stream is not reproducible)
+# ----------------------------------------------------------------------------------------------
+
+
+def philox_normal(seed: int, count: int) -> np.ndarray:
+    """Deterministic N(0,1) stream (numpy Philox bit generator, fixed seed)."""
+    return np.random.Generator(np.random.Philox(seed)).standard_normal(count)
+
+
+def make_scaled_problem(N, n, m=4, seed=42, with_constraint=False, skew=False, extra=None):
+    """Shape of the reference's scaling generator benchmark/problem_utils.jl:49-77:
+    components x[n], u[m], du[m], dt; [BilinearIntegrator(G,:x,:u), DerivativeIntegrator(:u,:du)];
+    QuadraticRegularizer(:u, 1.0); G ~ randn, x ~ randn, u ~ 0.1 randn, du ~ randn, dt = 0.1."""
+    z = n + 2 * m + 1
+    r = philox_normal(seed, (m + 1) * n * n + N * (n + 2 * m))
+    G = r[:(m + 1) * n * n].reshape(m + 1, n, n).transpose(0, 2, 1).copy()  # column-major fill
+    if skew:
+        G = (G - G.transpose(0, 2, 1)) / np.sqrt(2.0 * n)
+    rest = r[(m + 1) * n * n:]
+    x = rest[:n * N].reshape(N, n).T
+    u = 0.1 * rest[n * N:n * N + m * N].reshape(N, m).T
+    du = rest[n * N + m * N:].reshape(N, m).T
+    data = np.vstack([x, u, du, np.full((1, N), 0.1)])
+    Z0 = data.T.reshape(-1).copy()  # knot-major datavec
+    prob = Problem(
+        N=N, z=z, dt_idx=n + 2 * m,
+        integrators=[BilinearIntegrator(0, n, n, m, G), DerivativeIntegrator(n, m, n + m)],
+        objectives=[QuadraticRegularizer(n, m, np.ones(m))],
+        Z0=Z0)
+    if with_constraint:
+        prob.constraints = [KnotConstraint("norm", list(range(n, n + m)), 1.0,
+                                           list(range(2, N)), equality=False)]
+    return prob
+
+
+def make_readme_problem(seed=7):
+    """README.md:70-92 : x[2], u[1], dt; G = [-0.1 1; -1 -0.1] + u [0 1; 1 0]; QuadraticRegularizer(:u,1)."""
+    N = 50
+    r = philox_normal(seed, 3 * N)
+    data = np.vstack([r[:2 * N].reshape(N, 2).T, r[2 * N:].reshape(1, N), np.full((1, N), 0.1)])
+    G = np.array([[[-0.1, 1.0], [-1.0, -0.1]], [[0.0, 1.0], [1.0, 0.0]]])
+    return Problem(N=N, z=4, dt_idx=3,
+                   integrators=[BilinearIntegrator(0, 2, 2, 1, G)],
+                   objectives=[QuadraticRegularizer(2, 1, np.ones(1))],
+                   Z0=data.T.reshape(-1).copy())
+
+
+def pauli_generators():
+    """test/test_utils.jl:121-145."""
+    Gx = np.array([[0, 0, 0, 1], [0, 0, 1, 0], [0, -1, 0, 0], [-1, 0, 0, 0]], dtype=float)
+    Gy = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 0, -1], [0, 0, 1, 0]], dtype=float)
+    Gz = np.array([[0, 0, 1, 0], [0, 0, 0, -1], [-1, 0, 0, 0], [0, 1, 0, 0]], dtype=float)
+    return Gx, Gy, Gz
+
+
+def make_standard_problem(N=10, seed=3, omega=0.1):
+    """The reference's "standard problem" (test/test_snippets.jl:29-54, test/test_utils.jl:113-178)
+    minus its closure-based TerminalObjective (host-fallback scope): components x[4], u[2], du[2],
+    ddu[2], dt; Bilinear + 2 Derivative; QuadReg(u) + QuadReg(du) + MinimumTime; ||u|| - 1 <= 0 at
+    2:N-1.  Data are seeded here (the reference's are unseeded rand/randn)."""
+    Gx, Gy, Gz = pauli_generators()
+    G = np.stack([omega * Gz, Gx, Gy])
+    rng = np.random.Generator(np.random.Philox(seed))
+    x = 2 * rng.random((4, N)) - 1
+    u = 0.1 * (2 * rng.random((2, N)) - 1)
+    du = rng.standard_normal((2, N))
+    ddu = rng.standard_normal((2, N))
+    dt = 0.1 + 0.02 * rng.random((1, N))
+    data = np.vstack([x, u, du, ddu, dt])
+    return Problem(
+        N=N, z=11, dt_idx=10,
+        integrators=[BilinearIntegrator(0, 4, 4, 2, G), DerivativeIntegrator(4, 2, 6),
+                     DerivativeIntegrator(6, 2, 8)],
+        objectives=[QuadraticRegularizer(4, 2, np.ones(2)), QuadraticRegularizer(6, 2, np.ones(2)),
+                    MinimumTimeObjective(1.0)],
+        weights=[1.0, 1.0, 1.0],
+        constraints=[KnotConstraint("norm", [4, 5], 1.0, list(range(2, N)), equality=False)],
+        Z0=data.T.reshape(-1).copy())
+
+
+NAMED_TRAJECTORY_TYPE_1 = np.array([
+    [1.0, 0.957107, 0.853553, 0.75, 0.707107],
+    [0.0, 0.103553, 0.353553, 0.603553, 0.707107],
+    [0.0, 0.103553, 0.146447, 0.103553, 1.38778e-17],
+    [0.0, -0.25, -0.353553, -0.25, -1.52656e-16],
+    [0.0, 0.103553, 0.353553, 0.603553, 0.707107],
+    [1.0, 0.75, 0.146447, -0.457107, -0.707107],
+    [0.0, -0.25, -0.353553, -0.25, -1.249e-16],
+    [0.0, 0.603553, 0.853553, 0.603553, 4.16334e-16],
+    [0.0, -0.243953, 0.959151, -0.665253, 0.0],
+    [0.0, 0.0139165, 0.668917, 0.625329, 0.0],
+    [0.00393491, 0.0240775, -0.00942396, 0.00329391, 0.00941354],
+    [-0.00223794, -0.0105816, 0.00328457, 0.0204239, 0.0253415],
+    [0.0058186, 0.00686586, -0.00422555, 0.00442631, 0.000319156],
+    [-0.00134597, -0.00120682, 0.0114915, 0.00189333, -0.0251649],
+    [0.2, 0.2, 0.2, 0.2, 0.2],
+])
+"""The literal 15x5 data matrix of `named_trajectory_type_1` (test/test_utils.jl:57-82): a data
+fixture of the reference's own tests (components U[8], a[2], da[2], dda[2], dt[1])."""
+
+
+def make_type1_derivative_problem():
+    """`DerivativeIntegrator(:a, :da, traj)` on named_trajectory_type_1
+    (derivative_integrator.jl:118-123)."""
+    data = NAMED_TRAJECTORY_TYPE_1
+    return Problem(N=5, z=15, dt_idx=14, integrators=[DerivativeIntegrator(8, 2, 10)],
+                   objectives=[], Z0=data.T.reshape(-1).copy())

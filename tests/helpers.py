@@ -1,0 +1,91 @@
+"""Test helpers: convert an oracle `Problem` (oracle/dto_oracle.py) into the engine's host mirror."""
+import numpy as np
+
+import dto_amd
+import dto_oracle as O
+
+
+def to_engine(prob: O.Problem):
+    """Build NamedTrajectory + DirectTrajOptProblem (host mirror) describing the same problem."""
+    N, z = prob.N, prob.z
+    data = prob.Z0[:z * N].reshape(N, z).T
+    # one trajectory component per distinct range mentioned by the problem; leftovers become filler
+    ranges = {}
+    for it in prob.integrators:
+        ranges[(it.x_off, it.x_dim)] = None
+        if it.kind == "bilinear":
+            if it.u_dim:
+                ranges[(it.u_off, it.u_dim)] = None
+        else:
+            ranges[(it.xdot_off, it.x_dim)] = None
+    for t in prob.objectives:
+        if t.kind != "mintime":
+            ranges[(t.comp_off, t.comp_dim)] = None
+    ranges[(prob.dt_idx, 1)] = None
+    cuts = sorted(ranges)
+    comps, pos, names = {}, 0, {}
+    for off, d in cuts:
+        assert off >= pos, "overlapping component ranges are not representable"
+        if off > pos:
+            comps[f"_f{pos}"] = data[pos:off]
+        names[(off, d)] = f"c{off}"
+        comps[f"c{off}"] = data[off:off + d]
+        pos = off + d
+    if pos < z:
+        comps[f"_f{pos}"] = data[pos:z]
+    gdata = prob.Z0[z * N:] if prob.gd else None
+    traj = dto_amd.NamedTrajectory(comps, timestep=names[(prob.dt_idx, 1)], global_data=gdata)
+    assert traj.dim == z
+    integ = []
+    for it in prob.integrators:
+        if it.kind == "bilinear":
+            if it.u_dim == 0:
+                raise NotImplementedError
+            integ.append(dto_amd.BilinearIntegrator(it.G, names[(it.x_off, it.x_dim)], names[(it.u_off, it.u_dim)], traj))
+        else:
+            integ.append(dto_amd.DerivativeIntegrator(names[(it.x_off, it.x_dim)], names[(it.xdot_off, it.x_dim)], traj))
+    obj = dto_amd.NullObjective()
+    terms = []
+    for i, t in enumerate(prob.objectives):
+        if t.kind == "quadratic":
+            o = dto_amd.QuadraticRegularizer(names[(t.comp_off, t.comp_dim)], traj, t.R, baseline=t.baseline, times=t.times1)
+        elif t.kind == "linear":
+            o = dto_amd.LinearRegularizer(names[(t.comp_off, t.comp_dim)], traj, t.R, times=t.times1)
+        else:
+            o = dto_amd.MinimumTimeObjective(traj, D=t.D)
+        terms.append(prob.w(i) * o)
+    if terms:
+        obj = terms[0]
+        for t in terms[1:]:
+            obj = obj + t
+    cons = []
+    for c in prob.constraints:
+        # component indices are passed through a synthetic single name when they form one range
+        k = dto_amd.NonlinearKnotPointConstraint.__new__(dto_amd.NonlinearKnotPointConstraint)
+        k.kind, k.var_names, k.c, k.equality = c.kind, [], float(c.c), bool(c.equality)
+        k.times = np.asarray(c.times1, dtype=np.int64)
+        k.comps = np.asarray(c.comps, dtype=np.int32)
+        k.g_dim, k.var_dim = 1, k.comps.size
+        k.dim = k.times.size
+        cons.append(k)
+    return dto_amd.DirectTrajOptProblem(traj, obj, integ, constraints=cons)
+
+
+def rel_err(a, b):
+    """max |a-b| / max(1,|b|) elementwise (the tolerance form of SURVEY.md §8c)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def run_all(ev, prob_o, Z, mu, sigma=1.0, hessian=True):
+    """All MOI callbacks through the engine (host-pointer C ABI)."""
+    out = {}
+    out["f"] = ev.eval_objective(Z)
+    g = np.full(ev.shard.grad_len, np.nan); ev.eval_objective_gradient(g, Z); out["grad"] = g
+    c = np.full(ev.shard.cons_len, np.nan); ev.eval_constraint(c, Z); out["cons"] = c
+    j = np.full(ev.shard.jac_len, np.nan); ev.eval_constraint_jacobian(j, Z); out["jac"] = j
+    if hessian:
+        h = np.full(ev.shard.hess_len, np.nan); ev.eval_hessian_lagrangian(h, Z, sigma, mu); out["hess"] = h
+    return out

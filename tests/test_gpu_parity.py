@@ -1,0 +1,82 @@
+"""GPU parity: every MOI callback of the HIP engine (through the C ABI) against the oracle.
+
+Tolerances: values within 1e-10*max(1,|ref|) for objective, gradient, constraints
+and Jacobian, 1e-8*max(1,|ref|) for the Hessian; sparsity indices bit-exact."""
+import numpy as np
+import pytest
+
+import dto_oracle as O
+from helpers import rel_err, run_all, to_engine
+
+pytestmark = pytest.mark.gpu
+
+TOL, TOL_H = 1e-10, 1e-8
+
+
+def _check(prob_o, Z=None, seed=0, hessian=True, tag=""):
+    import dto_amd
+    ev_o = O.OracleEvaluator(prob_o)
+    ev = dto_amd.Evaluator(to_engine(prob_o), eval_hessian=hessian)
+    try:
+        assert ev.n_variables == prob_o.n_vars
+        assert ev.n_constraints == ev_o.n_constraints
+        assert ev.n_dynamics_constraints == ev_o.n_dynamics_constraints
+        jr, jc = ev.jacobian_structure()
+        r1, c1 = ev_o.jacobian_structure1()
+        assert np.array_equal(jr, r1) and np.array_equal(jc, c1), "Jacobian structure"
+        hr, hc = ev.hessian_lagrangian_structure()
+        r1, c1 = ev_o.hessian_structure1()
+        assert np.array_equal(hr, r1) and np.array_equal(hc, c1), "Hessian structure"
+        lo, hi = ev.constraint_bounds()
+        lo_o, hi_o = ev_o.row_bounds()
+        assert np.array_equal(lo, lo_o) and np.array_equal(hi, hi_o)
+        rng = np.random.default_rng(seed)
+        Z = prob_o.Z0.copy() if Z is None else Z
+        mu = rng.standard_normal(ev_o.n_constraints)
+        out = run_all(ev, prob_o, Z, mu, sigma=0.7, hessian=hessian)
+        errs = {
+            "f": rel_err(out["f"], ev_o.eval_objective(Z)),
+            "grad": rel_err(out["grad"], ev_o.eval_objective_gradient(Z)),
+            "cons": rel_err(out["cons"], ev_o.eval_constraint(Z)),
+            "jac": rel_err(out["jac"], ev_o.eval_constraint_jacobian(Z)),
+        }
+        if hessian:
+            errs["hess"] = rel_err(out["hess"], ev_o.eval_hessian_lagrangian(Z, 0.7, mu))
+        print(tag, errs, ev.last_stats())
+        for k, v in errs.items():
+            assert v <= (TOL_H if k == "hess" else TOL), (tag, k, v)
+    finally:
+        ev.close()
+
+
+def test_readme_problem():
+    _check(O.make_readme_problem(), tag="readme")
+
+
+def test_standard_problem():
+    _check(O.make_standard_problem(N=10), tag="standard")
+
+
+def test_type1_derivative_only():
+    _check(O.make_type1_derivative_problem(), tag="type1")
+
+
+@pytest.mark.parametrize("n,m,N", [(3, 1, 4), (8, 2, 6), (17, 3, 5), (64, 4, 6), (70, 2, 4)])
+def test_scaled_problems(n, m, N):
+    _check(O.make_scaled_problem(N, n, m, seed=n + N, with_constraint=True), tag=f"scaled{n}x{N}")
+
+
+def test_perturbed_point_and_large_norm():
+    p = O.make_scaled_problem(5, 16, 2, seed=11, with_constraint=True)
+    rng = np.random.default_rng(1)
+    Z = p.Z0 + 0.3 * rng.standard_normal(p.n_vars)
+    Z[p.dt_idx::p.z] = 0.9 + 0.2 * rng.random(p.N)  # big steps: ||dt G||_1 ~ 15, several squarings, q > 1
+    _check(p, Z=Z, tag="largenorm")
+
+
+def test_skew_generators_norm_preserved():
+    _check(O.make_scaled_problem(6, 32, 2, seed=5, skew=True), tag="skew")
+
+
+def test_jacobian_only_handle():
+    _check(O.make_scaled_problem(5, 8, 2, seed=2), hessian=False, tag="nohess")
