@@ -5,7 +5,7 @@ CSRC  := directtrajopt.jl_amd/csrc
 LIB   := directtrajopt.jl_amd/libdto_engine.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 
-all: $(LIB) oracle
+all: $(LIB)
 
 $(CSRC)/dto_kernels.o: $(CSRC)/dto_kernels.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -16,11 +16,7 @@ $(CSRC)/dto_engine.o: $(CSRC)/dto_engine.cpp $(CSRC)/dto_kernels.h include/dto_e
 $(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_engine.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-oracle:
-	$(MAKE) -C oracle
-
 clean:
 	rm -f $(CSRC)/*.o $(LIB)
-	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all clean

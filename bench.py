@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: knot-points/s of eval_constraint_jacobian, 256-state x 2000-knot bilinear
+(BASELINE.json `metric`, configs[2] shape; the reference's generator
+benchmark/problem_utils.jl:49-77, callback src/solvers/evaluator.jl:368-380).
+
+A "step" is one eval_constraint_jacobian call over the whole (per-GPU) trajectory with Z and the
+value vector resident in HBM.  With --gpus N each rank owns a contiguous knot range of an
+N*2000-knot problem (weak scaling, no data-path collective: every rank's output is one contiguous
+slab of the CSC value vector).
+
+Prints ONE JSON line on rank 0."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (AMD datasheet). The microarch
+# guide lists no f64 MFMA figure; tools/mfma_f64_rate.py measures the issue rate on the box.
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n, m, N, budget_s=20.0):
+    """The oracle ("port") timed on the host cores on a bounded sample of the same workload: the
+    bilinear Jacobian blocks (scipy expm + expm_frechet, oracle/dto_oracle.py) of the first knots of
+    the same synthetic problem, until `budget_s` seconds are spent.  BLAS threads = host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import dto_oracle as O
+    import dto_amd
+    G, x, u, du = dto_amd.host.synthetic.scaled_problem_arrays(N, n, m, 42)
+    z = n + 2 * m + 1
+    prob = O.Problem(N=N, z=z, dt_idx=z - 1, integrators=[O.BilinearIntegrator(0, n, n, m, G)], Z0=None)
+    integ = prob.integrators[0]
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    knots = 0
+    while knots < N - 1 and (time.perf_counter() - t0 < budget_s or knots < 2):
+        zk = np.concatenate([x[:, knots], u[:, knots], du[:, knots], [0.1]])
+        O.bilinear_block_jacobian(integ, prob, zk)
+        knots += 1
+    dt = time.perf_counter() - t0
+    return {"value": knots / dt, "unit": "knot-points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (scipy expm + {m} expm_frechet per knot) on the first {knots} of {N - 1} "
+                      f"intervals of the same problem, {dt:.1f} s, {threads} BLAS threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256, help="state dimension")
+    ap.add_argument("--m", type=int, default=4, help="number of drives")
+    ap.add_argument("--knots", type=int, default=2000, help="knots per GPU")
+    ap.add_argument("--callback", default="jacobian", choices=["jacobian", "hessian", "constraint"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import dto_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n, m, Nk = args.n, args.m, args.knots
+    N_total = Nk * world
+    prob = dto_amd.host.synthetic.make_scaled_problem(N_total, n, m, seed=42)
+    k_lo, k_hi = rank * Nk + 1, (rank + 1) * Nk
+    ev = dto_amd.Evaluator(prob, eval_hessian=(args.callback == "hessian"), device=local_rank, k_lo=k_lo, k_hi=k_hi)
+    Z = torch.from_numpy(prob.trajectory.vec()).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sh = ev.shard
+    if args.callback == "jacobian":
+        out = torch.empty(sh.jac_len, dtype=torch.float64, device=dev)
+        step = lambda: ev.eval_jacobian_dev(Z.data_ptr(), out.data_ptr(), stream)
+    elif args.callback == "hessian":
+        out = torch.empty(sh.hess_len, dtype=torch.float64, device=dev)
+        mu = torch.ones(ev.n_constraints, dtype=torch.float64, device=dev)
+        step = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), out.data_ptr(), stream)
+    else:
+        out = torch.empty(sh.cons_len, dtype=torch.float64, device=dev)
+        step = lambda: ev.eval_constraint_dev(Z.data_ptr(), out.data_ptr(), stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev.profile_reset()
+    ev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ev.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_gemm, n_gemm, fl_gemm = ev.profile_get("bgemm")
+    ms_sweep, n_sweep, fl_sweep = ev.profile_get("expmv")
+    smax, terms = ev.last_stats()
+    finite = bool(torch.isfinite(out).all().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        achieved = fl_gemm / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
+        line = {
+            "metric": "knot-points/sec for eval_constraint_jacobian, 256-state x 2000-knot bilinear"
+            if args.callback == "jacobian" else f"knot-points/sec for eval_{args.callback}",
+            "value": N_total * args.steps / elapsed,
+            "unit": "knot-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: {n}-state bilinear, {m} drives, N={Nk} knots per GPU "
+                                   f"(make_scaled_problem shape, Philox seed 42), callback={args.callback}",
+                       "state_dim": n, "drives": m, "knots_per_gpu": Nk, "knots_total": N_total,
+                       "parallelism": f"knot-range shards x{world}", "outputs_finite": finite,
+                       "max_squarings": smax, "sweep_terms": terms},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)",
+                "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": n_gemm, "avg_launch_ms": ms_gemm / max(n_gemm, 1),
+                "flops_per_launch": fl_gemm / max(n_gemm, 1),
+                "share_of_step": ms_gemm / (ms_per_step * args.steps) if ms_per_step > 0 else None,
+            },
+            "secondary_kernel": {"kernel": "k_sweep (generator sweep: exp(A)x and its u-tangents)",
+                                 "ms_per_step": ms_sweep / args.steps, "launches": n_sweep,
+                                 "achieved_tflops": fl_sweep / (ms_sweep * 1e-3) / 1e12 if ms_sweep > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.callback == "jacobian":
+            try:
+                line["cpu_baseline"] = cpu_baseline(n, m, Nk, args.cpu_budget)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "knot-points/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    ev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,4 +24,5 @@ from .host.problem import (  # noqa: F401
     DirectTrajOptProblem,
 )
 from .host.evaluator import Evaluator, EngineError, load_library, library_path  # noqa: F401
-from .host import capi  # noqa: F401
+from .host import capi, synthetic, distributed  # noqa: F401
+from . import host  # noqa: F401

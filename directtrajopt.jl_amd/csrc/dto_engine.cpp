@@ -86,6 +86,7 @@ struct ProfRec {
 struct dto_handle {
     std::string err;
     int device = 0;
+    bool structure_only = false;  // created with device < 0: sizes, structure and shard queries only
     int64_t N = 0, K = 0;
     int z = 0, gd = 0, dt_idx = 0, D = 0;
     int eval_hessian = 1;
@@ -127,6 +128,7 @@ struct dto_handle {
 };
 
 dto_handle::~dto_handle() {
+    if (structure_only) return;
     (void)hipSetDevice(device);
     for (auto& r : prof) {
         (void)hipEventDestroy(r.a);
@@ -316,7 +318,7 @@ SweepPlan plan_sweep(double beta) {
         p.q = 1; p.d_ub = 30;
         return p;
     }
-    const double theta_v = 7.0;  // cancellation budget e^7 ~ 1e3 (3 digits) on the Taylor sums
+    const double theta_v = 9.0;  // worst-case cancellation budget e^9 ~ 1e4 on the Taylor sums (tolerance 1e-10)
     p.q = std::max(1, (int)std::ceil(beta / theta_v));
     const double br = beta / p.q;
     int t = 8;
@@ -348,6 +350,14 @@ void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, con
             }
             launch_sweep_check(st, w, ty.T, t, 1.1e-16);
             buf ^= 1;
+            // every few steps look at the number of still-active column blocks (4 bytes) and stop
+            // enqueueing once every block has met the termination test
+            if (t >= 7 && (t % 4) == 3 && t + 1 < plan.d_ub) {
+                int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 6);
+                HIP_CHECK(hipMemcpyAsync(hs, w.stats, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (*hs == 0) break;
+            }
         }
     }
 }
@@ -358,8 +368,9 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
     b.chain.coef = own(h, dalloc<double>((size_t)cap * COEF_STRIDE));
     b.chain.s = own(h, dalloc<int32_t>(cap));
-    b.chain.smax = own(h, dalloc<int32_t>(1));
-    HIP_CHECK(hipMemset(b.chain.smax, 0, sizeof(int32_t)));
+    b.chain.smax = own(h, dalloc<int32_t>(4));
+    HIP_CHECK(hipMemset(b.chain.smax, 0, 4 * sizeof(int32_t)));
+    b.chain.d2max = reinterpret_cast<unsigned long long*>(b.chain.smax + 2);
     b.chain_cap = cap;
 }
 
@@ -376,16 +387,18 @@ int chunk_size(const dto_handle* h, int npad) {
 }
 
 // exp(dt G(u_k)) for every owned interval; -E_k goes straight into the Jacobian slab.
-void run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st) {
+// Returns max_k ||A_k^2||_1^(1/2) (exact), which bounds the growth of the Taylor terms of the sweep.
+double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st) {
     const int npad = b.k.npad;
     const int64_t nint = h->P.n_int;
-    if (nint <= 0) return;
+    double d2max = 0.0;
+    if (nint <= 0) return d2max;
     const int cap = b.chain_cap;
     int s_ub = 1;
     if (b1max == b1max && b1max > THETA_16) s_ub = std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
     s_ub = std::min(s_ub, 60);
     const double gemm_flops = 2.0 * npad * (double)npad * npad;
-    HIP_CHECK(hipMemsetAsync(b.chain.smax, 0, sizeof(int32_t), st));
+    h->last_smax = 0;
     for (int64_t c0 = 0; c0 < nint; c0 += cap) {
         const int nb = (int)std::min<int64_t>(cap, nint - c0);
         const int64_t int0 = h->P.kn_lo + c0;
@@ -395,18 +408,37 @@ void run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
         launch_norm1(st, npad, nb, w);
+        HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
         launch_expm_params(st, nb, s_ub, w);
+        // the number of squaring launches is data dependent: read back max/sum of s_k (8 bytes) while
+        // the Horner products run
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
+        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        hipEvent_t ev_s;
+        HIP_CHECK(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev_s, st));
         launch_poly_h3(st, npad, nb, w);
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 8); }
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
+        HIP_CHECK(hipEventSynchronize(ev_s));
+        HIP_CHECK(hipEventDestroy(ev_s));
+        const int s_max = hs[0];
+        {
+            double dv;
+            memcpy(&dv, hs + 2, sizeof(double));
+            d2max = (dv == dv) ? std::max(d2max, dv) : dv;
+        }
+        const double sq_flops = s_max > 0 ? gemm_flops * (double)hs[1] / s_max : 0.0;
+        h->last_smax = std::max(h->last_smax, s_max);
         int src = 4;
-        for (int it = 0; it < s_ub; ++it) {
-            ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb);
+        for (int it = 0; it < s_max; ++it) {
+            ProfScope ps(h, st, CAT_BGEMM, sq_flops);
             launch_bgemm_square(st, npad, nb, w, src, src == 4 ? 5 : 4, it, h->P, b.k, int0, vals);
             src = src == 4 ? 5 : 4;
         }
     }
+    return d2max;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -444,8 +476,10 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
         Bounds bd{0, 0};
         if (h->P.n_int > 0) {
             bd = get_bounds(h, b, dZ, st);
-            run_chain(h, b, dZ, dvals, bd.b1, st);
-            SweepPlan plan = plan_sweep(bd.beta);
+            const double d2 = run_chain(h, b, dZ, dvals, bd.b1, st);
+            // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
+            // (and still rigorous) growth rate for the sweep's step budget
+            SweepPlan plan = plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
             SweepTypes ty = make_types(b.k.m, false);
             run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
             launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
@@ -495,6 +529,7 @@ double* staging(dto_handle* h, size_t n) {
 template <class F>
 int guarded(dto_handle* h, F&& f) {
     if (!h) return fail(nullptr, "null handle");
+    if (h->structure_only) return fail(h, "structure-only handle (created with device < 0): no evaluation without a GPU");
     try {
         HIP_CHECK(hipSetDevice(h->device));
         f();
@@ -521,12 +556,7 @@ void check_sweeps(dto_handle* h) {
             if (st[0] != 0) throw HipError{"generator sweep did not converge within its step budget"};
         }
     }
-    h->last_smax = 0;
-    for (auto& b : h->bil) {
-        int32_t s = 0;
-        HIP_CHECK(hipMemcpy(&s, b.chain.smax, sizeof(s), hipMemcpyDeviceToHost));
-        h->last_smax = std::max(h->last_smax, (int)s);
-    }
+
 }
 
 }  // namespace
@@ -550,16 +580,22 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
     if (d->dt_idx < 0 || d->dt_idx >= d->z)
         return fail(nullptr, "dto_create: the timestep must be a trajectory component (bilinear_integrator.jl:123)");
     if (!d->Z0) return fail(nullptr, "dto_create: Z0 is required (constraint patterns are taken at Z0)");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(nullptr, "dto_create: no HIP device available (the engine has no CPU fallback)");
-    if (d->device < 0 || d->device >= ndev) return fail(nullptr, "dto_create: bad device ordinal");
+    const bool sonly = d->device < 0;  // structure-only handle: no GPU is touched, evaluations fail
+    if (!sonly) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(nullptr, "dto_create: no HIP device available (the engine has no CPU fallback)");
+        if (d->device >= ndev) return fail(nullptr, "dto_create: bad device ordinal");
+    }
 
     dto_handle* h = new dto_handle();
     try {
         h->device = d->device;
-        HIP_CHECK(hipSetDevice(h->device));
-        HIP_CHECK(hipStreamCreate(&h->stream));
+        h->structure_only = sonly;
+        if (!sonly) {
+            HIP_CHECK(hipSetDevice(h->device));
+            HIP_CHECK(hipStreamCreate(&h->stream));
+        }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;
         h->n_vars = (int64_t)d->z * d->N + d->gd;
@@ -597,8 +633,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                         }
                         b.g1[j] = std::max(b.g1[j], cs);
                     }
-                b.k.G = own(h, dupload(G));
-                b.k.GT = own(h, dupload(GT));
+                if (!sonly) {
+                    b.k.G = own(h, dupload(G));
+                    b.k.GT = own(h, dupload(GT));
+                }
                 h->integ_index.push_back((int)h->bil.size());
                 h->bil.push_back(std::move(b));
             } else if (s.kind == DTO_INTEGRATOR_DERIVATIVE) {
@@ -647,8 +685,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         P.n_int = std::max<int64_t>(0, std::min<int64_t>(h->k_hi, h->K) - h->k_lo + 1);
 
         build_structure(h, d->Z0);
-        h->d_colptr = own(h, dupload(h->colptr));
-        P.colptr = h->d_colptr;
+        if (!sonly) {
+            h->d_colptr = own(h, dupload(h->colptr));
+            P.colptr = h->d_colptr;
+        }
         const int64_t c_lo = P.kn_lo * h->z, c_hi = (P.kn_lo + P.n_knots) * h->z;
         P.jac_lo = h->colptr[c_lo];
         P.hess_lo = hess_block_start(h, P.kn_lo);
@@ -699,18 +739,20 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             }
             c.k.n_times = (int64_t)times.size();
             c.k.mu_off = c.row_off;
-            c.k.comps = own(h, dupload(c.comps));
-            c.k.times = own(h, dupload(times));
-            c.k.lrow = own(h, dupload(lrows));
-            c.k.tidx = own(h, dupload(tidx));
-            c.k.jpos = own(h, dupload(jpos));
+            if (!sonly) {
+                c.k.comps = own(h, dupload(c.comps));
+                c.k.times = own(h, dupload(times));
+                c.k.lrow = own(h, dupload(lrows));
+                c.k.tidx = own(h, dupload(tidx));
+                c.k.jpos = own(h, dupload(jpos));
+            }
         }
         h->cons_len = lrow;
         I.cons_len = lrow;
         I.n_row_segments = (int32_t)h->row_segments.size();
 
         // objectives
-        for (int i = 0; i < d->n_objectives; ++i) {
+        for (int i = 0; i < d->n_objectives && !sonly; ++i) {
             const dto_objective_desc& s = d->objectives[i];
             KObj o{};
             o.kind = s.kind; o.weight = s.weight; o.D = s.D;
@@ -744,13 +786,17 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             h->obj.push_back(o);
         }
 
+        if (sonly) {
+            *out = h;
+            return 0;
+        }
         // scratch
         h->d_Z = own(h, dalloc<double>(h->n_vars));
         h->d_mu = own(h, dalloc<double>(std::max<int64_t>(h->n_cons, 1)));
         h->d_partial = own(h, dalloc<double>(256));
         h->d_f = own(h, dalloc<double>(1));
         h->d_bounds = own(h, dalloc<double>(2));
-        HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 4 * sizeof(double)));
+        HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 8 * sizeof(double)));
 
         // per-bilinear workspaces + generator product norms (for the step-budget bounds)
         for (auto& b : h->bil) {

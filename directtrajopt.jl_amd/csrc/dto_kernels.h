@@ -82,7 +82,8 @@ struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices 
     double* norms;   // [C][4]
     double* coef;    // [C][COEF_STRIDE]
     int32_t* s;      // [C] squarings per interval
-    int32_t* smax;   // [1] max over the call (stats)
+    int32_t* smax;   // [0] max, [1] sum of s over the chunk (read back by the host before the squarings)
+    unsigned long long* d2max;  // bit pattern of max_k ||A_k^2||_1^(1/2) over the chunk (exact; plans the sweep)
 };
 
 void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, int64_t int0, int nb, double* A);

@@ -19,6 +19,8 @@
 #include "dto_gemm.hip.h"
 #include "dto_kernels.h"
 
+#include <cstdlib>
+
 namespace dto {
 
 // ============================================================================================
@@ -287,7 +289,9 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     }
     if (!(alpha == alpha) || s > s_cap) s = s_cap;  // NaN/Inf input: bounded work, NaN propagates
     w.s[b] = s;
-    atomicMax(w.smax, s);
+    atomicMax(&w.smax[0], s);
+    atomicAdd(&w.smax[1], s);
+    atomicMax(w.d2max, dbits(d2v));
     const double sigma = ldexp(1.0, -s);
     double c = 1.0;
     double* cf = w.coef + (int64_t)b * COEF_STRIDE;
@@ -430,7 +434,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {
     const int rt = blockIdx.x % row_tiles;
     const int ct = blockIdx.x / row_tiles;
     const int ty = blockIdx.y;  // column type (mode 0) or generator index (mode 1)
-    if (a.mode == 0 && !a.w.active[ct]) return;
+    if (a.mode == 0 && !a.w.active[(ct * TN) / a.w.TN]) return;
     const int64_t nn = (int64_t)npad * npad;
     const int64_t typesz = (int64_t)Kpad * npad;
     const int m = a.B.m;
@@ -509,12 +513,28 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {
         }
 }
 
+static int sweep_tile_choice() {
+    static int v = [] { const char* e = getenv("DTO_SWEEP_TILE"); return e ? atoi(e) : -1; }();
+    return v;
+}
 static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
     const int npad = a.w.npad;
-    if (npad % 128 == 0 && a.w.TN == 128) {
-        hipLaunchKernelGGL((k_sweep<128, 128>), dim3((npad / 128) * (a.w.Kpad / 128), ny), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((k_sweep<64, 64>), dim3((npad / 64) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
+    // tile choice: enough workgroups to cover 256 CUs a few times over (the per-step GEMM is small)
+    int choice = sweep_tile_choice();
+    if (choice < 0) choice = (npad % 128 == 0 && a.w.TN == 128) ? 1 : 0;
+    if (npad % 128 != 0 || a.w.TN != 128) choice = 0;
+    switch (choice) {
+        case 3:
+            hipLaunchKernelGGL((k_sweep<128, 128>), dim3((npad / 128) * (a.w.Kpad / 128), ny), dim3(256), 0, st, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((k_sweep<64, 128>), dim3((npad / 64) * (a.w.Kpad / 128), ny), dim3(256), 0, st, a);
+            break;
+        case 1:
+            hipLaunchKernelGGL((k_sweep<128, 64>), dim3((npad / 128) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
+            break;
+        default:
+            hipLaunchKernelGGL((k_sweep<64, 64>), dim3((npad / 64) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
     }
 }
 

@@ -1,0 +1,204 @@
+"""Pins the oracle (oracle/dto_oracle.py) WITHOUT the reference runtime (no julia here):
+  * the one literal fixture of the reference's tests (named_trajectory_type_1,
+    test/test_utils.jl:57-82) with the closed-form DerivativeIntegrator answers
+    (derivative_integrator.jl:45, 68-116);
+  * complex-step differentiation (first order) and 60-digit mpmath differentiation (second order)
+    of x_{k+1} - exp(dt G(u)) x_k  (bilinear_integrator.jl:81);
+  * invariants of the reference's Pauli-generator problem (test/test_utils.jl:121-145);
+  * the reference's own finite-difference bars (evaluator.jl:752 atol=rtol=1e-6; :790 atol=1e-2);
+  * the closed-form index layout of SURVEY.md §3.6 against the literal re-enactment of
+    evaluator.jl:119-209."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+import dto_oracle as O
+
+
+def test_type1_derivative_closed_form():
+    p = O.make_type1_derivative_problem()
+    data = O.NAMED_TRAJECTORY_TYPE_1
+    a, da, dt = data[8:10], data[10:12], data[14]
+    ev = O.OracleEvaluator(p)
+    g = ev.eval_constraint(p.Z0)
+    want = np.concatenate([a[:, k + 1] - a[:, k] - dt[k] * da[:, k] for k in range(4)])
+    assert np.array_equal(g, want)
+    # a literal spot value: knot 2 -> 3, component a_1:  0.959151 - (-0.243953) - 0.2*0.0240775
+    assert g[2] == pytest.approx(0.959151 + 0.243953 - 0.2 * 0.0240775, abs=1e-15)
+    rows, cols = ev.jacobian_structure1()
+    vals = ev.eval_constraint_jacobian(p.Z0)
+    assert len(vals) == 2 * 15 * 2 * 4  # 2 z D K
+    J = np.zeros((8, 75))
+    J[rows - 1, cols - 1] = vals
+    for k in range(4):
+        blk = J[2 * k:2 * k + 2, 15 * k:15 * k + 30]
+        exp = np.zeros((2, 30))
+        exp[:, 8:10] = -np.eye(2)
+        exp[:, 10:12] = -dt[k] * np.eye(2)
+        exp[:, 14] = -da[:, k]
+        exp[:, 15 + 8:15 + 10] = np.eye(2)
+        assert np.array_equal(blk, exp)
+    mu = np.arange(1.0, 9.0)
+    hr, hc = ev.hessian_structure1()
+    H = ev.eval_hessian_lagrangian(p.Z0, 1.0, mu)
+    nz = {(int(r), int(c)): v for r, c, v in zip(hr, hc, H) if v != 0}
+    exp = {}
+    for k in range(4):
+        for i in range(2):
+            exp[(15 * k + 11 + i, 15 * k + 15)] = -mu[2 * k + i]  # (da_i, dt) cross term, 1-based
+    assert nz == exp
+
+
+def test_csc_order_matches_closed_form():
+    """column (k,j) stores, for each integrator, interval k-1 rows then interval k rows."""
+    for (N, n, m) in [(5, 2, 1), (6, 3, 2), (4, 4, 2)]:
+        p = O.make_scaled_problem(N, n, m, seed=1)
+        ev = O.OracleEvaluator(p)
+        rows, cols = ev.jacobian_structure1()
+        z, K = p.z, N - 1
+        dims = [n, m]
+        offs = [0, n * K]
+        er, ec = [], []
+        for k in range(1, N + 1):
+            for j in range(1, z + 1):
+                for d, off in zip(dims, offs):
+                    for kk in (k - 1, k):
+                        if 1 <= kk <= K:
+                            for r in range(1, d + 1):
+                                er.append(off + (kk - 1) * d + r)
+                                ec.append((k - 1) * z + j)
+        assert np.array_equal(rows, er) and np.array_equal(cols, ec)
+        assert len(rows) == 2 * z * sum(dims) * K
+        hr, hc = ev.hessian_structure1()
+        er, ec = [], []
+        for k in range(1, N + 1):
+            for j in range(1, z + 1):
+                if k >= 2:
+                    for i in range(1, z + 1):
+                        er.append((k - 2) * z + i); ec.append((k - 1) * z + j)
+                for i in range(1, j + 1):
+                    er.append((k - 1) * z + i); ec.append((k - 1) * z + j)
+        assert np.array_equal(hr, er) and np.array_equal(hc, ec)
+        assert len(hr) == N * z * (z + 1) // 2 + K * z * z
+
+
+def _f_complex(integ, prob, zk):
+    n, m = integ.x_dim, integ.u_dim
+    dt = zk[prob.dt_idx]
+    x = zk[integ.x_off:integ.x_off + n]
+    u = zk[integ.u_off:integ.u_off + m]
+    Gu = integ.G[0] + np.tensordot(u, integ.G[1:], axes=(0, 0))
+    return -sla.expm(dt * Gu) @ x
+
+
+def test_bilinear_jacobian_complex_step():
+    p = O.make_scaled_problem(3, 6, 3, seed=9)
+    integ = p.integrators[0]
+    zk = p.Z0[:p.z].copy()
+    zk[p.dt_idx] = 0.37
+    B = O.bilinear_block_jacobian(integ, p, zk)
+    h = 1e-30
+    for j in range(p.z):
+        zc = zk.astype(complex)
+        zc[j] += 1j * h
+        col = _f_complex(integ, p, zc).imag / h
+        assert np.max(np.abs(col - B[:, j])) <= 1e-13 * max(1.0, np.abs(col).max())
+
+
+def test_bilinear_hessian_mpmath():
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 60
+    rng = np.random.default_rng(4)
+    n, m = 2, 2
+    G = rng.standard_normal((m + 1, n, n))
+    p = O.Problem(N=2, z=n + m + 1, dt_idx=n + m, integrators=[O.BilinearIntegrator(0, n, n, m, G)],
+                  Z0=np.zeros(2 * (n + m + 1)))
+    zk = np.concatenate([rng.standard_normal(n), 0.4 * rng.standard_normal(m), [0.3]])
+    mu = rng.standard_normal(n)
+    H = O.bilinear_block_hessian(p.integrators[0], p, zk, mu)
+    Gm = [mp.matrix(G[j].tolist()) for j in range(m + 1)]
+
+    def phi(*zz):
+        x = mp.matrix(zz[:n])
+        Gu = Gm[0] + sum((zz[n + j] * Gm[1 + j] for j in range(m)), mp.zeros(n))
+        E = mp.expm(zz[n + m] * Gu)
+        y = E * x
+        return -sum(mp.mpf(mu[i]) * y[i] for i in range(n))
+
+    z0 = [mp.mpf(v) for v in zk]
+    nz = len(z0)
+    for a in range(nz):
+        for b in range(a, nz):
+            order = [0] * nz
+            order[a] += 1
+            order[b] += 1
+            ref = mp.diff(phi, tuple(z0), tuple(order))
+            assert abs(float(ref) - H[a, b]) <= 1e-11 * max(1.0, abs(float(ref))), (a, b)
+            assert H[a, b] == pytest.approx(H[b, a], abs=1e-13)
+
+
+def test_pauli_problem_invariants():
+    p = O.make_standard_problem(N=8)
+    integ = p.integrators[0]
+    for G in integ.G:
+        assert np.array_equal(G, -G.T)  # skew-symmetric generators: exp is orthogonal
+    for k in range(p.K):
+        zk = p.Z0[k * p.z:(k + 1) * p.z]
+        B = O.bilinear_block_jacobian(integ, p, zk)
+        E = -B[:, :4]
+        assert np.allclose(E.T @ E, np.eye(4), atol=1e-14)
+    g = O.integrator_evaluate(integ, p, p.Z0)
+    for k in range(p.K):
+        xk = p.Z0[k * p.z:k * p.z + 4]
+        xk1 = p.Z0[(k + 1) * p.z:(k + 1) * p.z + 4]
+        assert np.linalg.norm(xk1 - g[4 * k:4 * k + 4]) == pytest.approx(np.linalg.norm(xk), rel=1e-13)
+
+
+def test_reference_finite_difference_bars():
+    """The reference's own acceptance tests of this path are FD comparisons: Jacobian atol=rtol=1e-6
+    (evaluator.jl:752), Hessian atol=1e-2 (:790), gradient `≈`.  The oracle passes them with margin."""
+    p = O.make_standard_problem(N=6, seed=5)
+    ev = O.OracleEvaluator(p)
+    Z = p.Z0.copy()
+    nv = p.n_vars
+    eps = 1e-6
+    rows, cols = ev.jacobian_structure1()
+    J = np.zeros((ev.n_constraints, nv))
+    J[rows - 1, cols - 1] = ev.eval_constraint_jacobian(Z)
+    Jfd = np.stack([(ev.eval_constraint(Z + eps * e) - ev.eval_constraint(Z - eps * e)) / (2 * eps)
+                    for e in np.eye(nv)], axis=1)
+    assert np.allclose(J, Jfd, atol=1e-6, rtol=1e-6)
+    mu = np.random.default_rng(0).standard_normal(ev.n_constraints)
+
+    def gradL(zv):
+        M = np.zeros((ev.n_constraints, nv))
+        M[rows - 1, cols - 1] = ev.eval_constraint_jacobian(zv)
+        return ev.eval_objective_gradient(zv) + M.T @ mu
+
+    hr, hc = ev.hessian_structure1()
+    Hu = np.zeros((nv, nv))
+    Hu[hr - 1, hc - 1] = ev.eval_hessian_lagrangian(Z, 1.0, mu)
+    Hs = Hu + np.triu(Hu, 1).T
+    Hfd = np.stack([(gradL(Z + eps * e) - gradL(Z - eps * e)) / (2 * eps) for e in np.eye(nv)], axis=1)
+    assert np.allclose(Hs, Hfd, atol=1e-5)
+    gfd = np.array([(ev.eval_objective(Z + eps * e) - ev.eval_objective(Z - eps * e)) / (2 * eps) for e in np.eye(nv)])
+    assert np.allclose(gfd, ev.eval_objective_gradient(Z), atol=1e-8)
+
+
+def test_quadratic_regularizer_follows_code_not_docstring():
+    """regularizers.jl:86-87 weights by dt^2 (the docstring says dt); (v,dt) Hessian entries survive
+    only when the timestep follows v in the knot (regularizers.jl:160 + evaluator.jl:637)."""
+    N, z = 3, 3
+    data = np.array([[1.0, 2.0, 3.0], [0.5, 0.5, 0.5], [4.0, 5.0, 6.0]])  # comps: v, dt, w
+    Z = data.T.reshape(-1)
+    base = dict(N=N, z=z, dt_idx=1, integrators=[O.DerivativeIntegrator(0, 1, 2)], Z0=Z)
+    pv = O.Problem(objectives=[O.QuadraticRegularizer(0, 1, np.array([2.0]))], **base)
+    pw = O.Problem(objectives=[O.QuadraticRegularizer(2, 1, np.array([2.0]))], **base)
+    assert O.objective_value(pv, Z) == pytest.approx(sum(0.5 * 2.0 * (0.5 * v) ** 2 for v in (1, 2, 3)))
+    for prob, v_idx, keeps in ((pv, 0, True), (pw, 2, False)):
+        ev = O.OracleEvaluator(prob)
+        hr, hc = ev.hessian_structure1()
+        H = ev.eval_hessian_lagrangian(Z, 1.0, np.zeros(ev.n_constraints))
+        d = {(int(r), int(c)): v for r, c, v in zip(hr, hc, H)}
+        lo, hi = sorted((v_idx + 1, 2))
+        assert (d[(lo, hi)] != 0.0) == keeps
