@@ -521,7 +521,7 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
     const int npad = a.w.npad;
     // tile choice: enough workgroups to cover 256 CUs a few times over (the per-step GEMM is small)
     int choice = sweep_tile_choice();
-    if (choice < 0) choice = (npad % 128 == 0 && a.w.TN == 128) ? 1 : 0;
+    if (choice < 0) choice = 0;  // 64x64 measured fastest at 256x2000 (2.5 workgroups per CU)
     if (npad % 128 != 0 || a.w.TN != 128) choice = 0;
     switch (choice) {
         case 3:
