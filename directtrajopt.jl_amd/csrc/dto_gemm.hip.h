@@ -156,14 +156,13 @@ struct GemmCoord {
 // observed round-robin dispatch, so the tiles of one matrix are given ids that differ by multiples
 // of 8 and sit next to each other in dispatch order: they then re-use each other's A/B panels from
 // the same XCD's L2.  Placement only affects speed, never correctness.
-__device__ __forceinline__ bool decode_batch_tile(int nbatch, int tiles_per_mat, int& batch, int& tile) {
-    const int wg = blockIdx.x;
+__device__ __forceinline__ bool decode_batch_tile(int wg, int nbatch, int tiles_per_mat, int& batch, int& tile) {
     const int xcd = wg & 7;
     const int idx = wg >> 3;
     batch = (idx / tiles_per_mat) * 8 + xcd;
     tile = idx % tiles_per_mat;
     return batch < nbatch;
 }
-inline int batch_tile_grid(int nbatch, int tiles_per_mat) { return ((nbatch + 7) / 8) * 8 * tiles_per_mat; }
+__host__ __device__ inline int batch_tile_count(int nbatch, int tiles_per_mat) { return ((nbatch + 7) / 8) * 8 * tiles_per_mat; }
 
 }  // namespace dto

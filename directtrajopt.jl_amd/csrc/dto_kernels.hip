@@ -147,86 +147,105 @@ struct BGemmArgs {
 };
 
 // Batched C_b = A_b * B_b over nbatch intervals, npad x npad x npad each (FP64 MFMA).
+// PERSISTENT: the grid is sized to the chip (2 workgroups per CU) and every workgroup walks the
+// (interval, tile) list with a stride of gridDim.x; this removes the workgroup re-dispatch gaps that a
+// one-tile-per-workgroup grid of ~8000 short workgroups shows (measured: 25 % of wall time).
 template <int T, int EPI>
 __global__ void __launch_bounds__(256, 2) k_bgemm(BGemmArgs a) {
     using Cfg = GemmCfg<T, T>;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
     const int tiles_1d = a.npad / T;
-    int b, tile;
-    if (!decode_batch_tile(a.nbatch, tiles_1d * tiles_1d, b, tile)) return;
-    int s_b = 0;
-    if (EPI == EPI_SQUARE) {
-        s_b = a.s[b];
-        if (a.it >= s_b) return;  // this interval needs no further squaring
-    }
-    const int tr = tile % tiles_1d, tc = tile / tiles_1d;
+    const int tpm = tiles_1d * tiles_1d;
+    const int total = batch_tile_count(a.nbatch, tpm);
     const int64_t nn = (int64_t)a.npad * a.npad;
-    const double* Ab = a.A + b * nn + (int64_t)tr * T;
-    const double* Bb = a.B + b * nn + (int64_t)tc * T * a.npad;
-
-    GemmAcc<T, T> acc;
-    acc.zero();
-    gemm_accumulate<T, T>(acc, Ab, a.npad, Bb, a.npad, a.npad, nullptr, smem);
-
     GemmCoord<T, T> co;
-    const int row0 = tr * T + co.row_base, col0 = tc * T + co.col_base;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        int b, tile;
+        if (!decode_batch_tile(v, a.nbatch, tpm, b, tile)) continue;
+        int s_b = 0;
+        if (EPI == EPI_SQUARE) {
+            s_b = a.s[b];
+            if (a.it >= s_b) continue;  // this interval needs no further squaring
+        }
+        const int tr = tile % tiles_1d, tc = tile / tiles_1d;
+        const double* Ab = a.A + b * nn + (int64_t)tr * T;
+        const double* Bb = a.B + b * nn + (int64_t)tc * T * a.npad;
 
-    if (EPI == EPI_SQUARE && a.it == s_b - 1) {
-        // last squaring: the product is E_k; store -E_k into the Jacobian slab (x_k columns of the
-        // interval's own rows), evaluator.jl:514-525 / bilinear_integrator.jl:111-131
-        const int64_t kn = a.int0 + b;
-        const int n = a.Bi.n;
+        GemmAcc<T, T> acc;
+        acc.zero();
+        gemm_accumulate<T, T>(acc, Ab, a.npad, Bb, a.npad, a.npad, nullptr, smem);
+
+        const int row0 = tr * T + co.row_base, col0 = tc * T + co.col_base;
+
+        if (EPI == EPI_SQUARE && a.it == s_b - 1) {
+            // last squaring: the product is E_k; store -E_k into the Jacobian slab (x_k columns of the
+            // interval's own rows), evaluator.jl:514-525 / bilinear_integrator.jl:111-131
+            const int64_t kn = a.int0 + b;
+            const int n = a.Bi.n;
+#pragma unroll
+            for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = col0 + 16 * tj + 4 * r;
+                    if (col >= n) continue;
+                    const int64_t base = jac_pos(a.P, a.P.colptr, kn, a.Bi.x_off + col, a.Bi.pre, n, 1, 0);
+#pragma unroll
+                    for (int ti = 0; ti < Cfg::MT; ++ti) {
+                        const int row = row0 + 16 * ti;
+                        if (row < n) a.vals[base + row] = -acc.v[ti][tj][r];
+                    }
+                }
+            continue;
+        }
+
+        double* Cb = a.C + b * nn;
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr;
+        if (EPI == EPI_HORNER) {
+            const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
+            c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3];
+            M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn;
+        }
 #pragma unroll
         for (int tj = 0; tj < Cfg::NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = col0 + 16 * tj + 4 * r;
-                if (col >= n) continue;
-                const int64_t base = jac_pos(a.P, a.P.colptr, kn, a.Bi.x_off + col, a.Bi.pre, n, 1, 0);
 #pragma unroll
                 for (int ti = 0; ti < Cfg::MT; ++ti) {
                     const int row = row0 + 16 * ti;
-                    if (row < n) a.vals[base + row] = -acc.v[ti][tj][r];
+                    const int64_t off = (int64_t)col * a.npad + row;
+                    double v2 = acc.v[ti][tj][r];
+                    if (EPI == EPI_HORNER) {
+                        v2 += c1 * M1[off] + c2 * M2[off] + c3 * M3[off];
+                        if (row == col) v2 += c0;
+                    }
+                    Cb[off] = v2;
                 }
             }
-        return;
     }
-
-    double* Cb = a.C + b * nn;
-    double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr;
-    if (EPI == EPI_HORNER) {
-        const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
-        c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3];
-        M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn;
-    }
-#pragma unroll
-    for (int tj = 0; tj < Cfg::NT; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = col0 + 16 * tj + 4 * r;
-#pragma unroll
-            for (int ti = 0; ti < Cfg::MT; ++ti) {
-                const int row = row0 + 16 * ti;
-                const int64_t off = (int64_t)col * a.npad + row;
-                double v = acc.v[ti][tj][r];
-                if (EPI == EPI_HORNER) {
-                    v += c1 * M1[off] + c2 * M2[off] + c3 * M3[off];
-                    if (row == col) v += c0;
-                }
-                Cb[off] = v;
-            }
-        }
 }
 
+static int bgemm_grid_cap() {
+    // persistent grid: workgroups per CU x 256 CUs (multiple of 8 so the XCD label of a workgroup is
+    // the same for every tile it walks); DTO_BGEMM_WGS_PER_CU=0 restores one workgroup per tile
+    static int v = [] { const char* e = getenv("DTO_BGEMM_WGS_PER_CU"); return e ? atoi(e) : 2; }();
+    return v * 256;
+}
 template <int EPI>
 static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
+    const int cap = bgemm_grid_cap();
     if (a.npad % 128 == 0) {
         const int t1 = a.npad / 128;
-        hipLaunchKernelGGL((k_bgemm<128, EPI>), dim3(batch_tile_grid(a.nbatch, t1 * t1)), dim3(256), 0, st, a);
+        int grid = batch_tile_count(a.nbatch, t1 * t1);
+        if (cap > 0 && grid > cap) grid = cap;
+        hipLaunchKernelGGL((k_bgemm<128, EPI>), dim3(grid), dim3(256), 0, st, a);
     } else {
         const int t1 = a.npad / 64;
-        hipLaunchKernelGGL((k_bgemm<64, EPI>), dim3(batch_tile_grid(a.nbatch, t1 * t1)), dim3(256), 0, st, a);
+        int grid = batch_tile_count(a.nbatch, t1 * t1);
+        const int cap64 = cap * 2;  // 64x64 tiles: 4 workgroups per CU fit
+        if (cap > 0 && grid > cap64) grid = cap64;
+        hipLaunchKernelGGL((k_bgemm<64, EPI>), dim3(grid), dim3(256), 0, st, a);
     }
 }
 
