@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,8 @@ struct BilHost {
     double* d_n2 = nullptr;
     ChainWork chain{};
     int chain_cap = 0;
+    bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
+    BasisSet basis[3]{};      // degrees 2, 3, 4
 };
 
 struct ConHost {
@@ -362,6 +365,61 @@ void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, con
     }
 }
 
+// multisets of size r over {0..m} as sorted tuples, lexicographic
+void enum_multisets(int m1, int r, std::vector<int>& cur, int start, std::vector<std::vector<int>>& out) {
+    if ((int)cur.size() == r) { out.push_back(cur); return; }
+    for (int i = start; i < m1; ++i) {
+        cur.push_back(i);
+        enum_multisets(m1, r, cur, i, out);
+        cur.pop_back();
+    }
+}
+
+// S_alpha = sum over distinct first letters i of alpha of G_i * S_(alpha minus i): built once at create with
+// the engine's own batched GEMM (one product per (alpha, i)).
+void build_basis(dto_handle* h, BilHost& b, int cap) {
+    const int m1 = b.k.m + 1, npad = b.k.npad;
+    const size_t nn = (size_t)npad * npad;
+    std::vector<std::vector<std::vector<int>>> sets(5);
+    std::vector<std::map<std::vector<int>, int>> index(5);
+    for (int r = 1; r <= 4; ++r) {
+        std::vector<int> cur;
+        enum_multisets(m1, r, cur, 0, sets[r]);
+        for (size_t a = 0; a < sets[r].size(); ++a) index[r][sets[r][a]] = (int)a;
+    }
+    double* tmp = own(h, dalloc<double>(nn));
+    std::vector<double*> S(5, nullptr);
+    S[1] = const_cast<double*>(b.k.G);
+    for (int r = 2; r <= 4; ++r) {
+        const int cnt = (int)sets[r].size(), cntpad = ((cnt + 15) / 16) * 16;
+        S[r] = own(h, dalloc<double>(nn * cntpad));
+        HIP_CHECK(hipMemsetAsync(S[r], 0, nn * cntpad * sizeof(double), h->stream));
+        std::vector<int32_t> idx;
+        for (int a = 0; a < cnt; ++a) {
+            const std::vector<int>& al = sets[r][a];
+            for (int v : al) idx.push_back(v);
+            int last = -1;
+            for (size_t p = 0; p < al.size(); ++p) {
+                const int i = al[p];
+                if (i == last) continue;  // distinct first letters only
+                last = i;
+                std::vector<int> rest = al;
+                rest.erase(rest.begin() + p);
+                const double* prev = S[r - 1] + (size_t)index[r - 1][rest] * nn;
+                launch_bgemm_plain(h->stream, npad, 1, b.k.G + (size_t)i * nn, prev, tmp);
+                launch_add(h->stream, S[r] + (size_t)a * nn, tmp, (int64_t)nn);
+            }
+        }
+        BasisSet& bs = b.basis[r - 2];
+        bs.r = r; bs.cnt = cnt; bs.cntpad = cntpad; bs.S = S[r];
+        bs.idx = own(h, dupload(idx));
+        const int cappad = ((cap + 127) / 128) * 128;
+        bs.coef = own(h, dalloc<double>((size_t)cappad * cntpad));
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    b.use_basis = true;
+}
+
 void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     const size_t nn = (size_t)b.k.npad * b.k.npad;
     for (int i = 0; i < 6; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
@@ -404,9 +462,18 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
         launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
-        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
-        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
-        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
+        if (b.use_basis) {
+            const int nbpad = ((nb + 127) / 128) * 128;
+            for (int r = 0; r < 3; ++r) {
+                launch_basis_coef(st, h->P, b.k, b.basis[r], dZ, int0, nb, nbpad);
+                ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis[r].cntpad * nb);
+                launch_basis_gemm(st, npad, nb, nbpad, b.basis[r], w.W[1 + r]);
+            }
+        } else {
+            { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
+            { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
+            { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
+        }
         launch_norm1(st, npad, nb, w);
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
         launch_expm_params(st, nb, s_ub, w);
@@ -824,6 +891,16 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             for (int i = 0; i < nb; ++i) b.n2[i] = norms[(size_t)i * 4 + 1];
             b.d_g1 = own(h, dupload(b.g1));
             b.d_n2 = own(h, dupload(b.n2));
+            // generator-subspace powers pay off while the number of symmetrised products stays well
+            // below the 3n columns the three GEMMs would process (DTO_BASIS_POWERS=0/1 overrides)
+            {
+                long cnt = 0;
+                long c2 = (long)m1 * (m1 + 1) / 2, c3 = c2 * (m1 + 2) / 3, c4 = c3 * (m1 + 3) / 4;
+                cnt = c2 + c3 + c4;
+                bool want = npad % 128 == 0 && cnt * 2 <= 3L * npad;
+                if (const char* e = getenv("DTO_BASIS_POWERS")) want = atoi(e) != 0 && npad % 128 == 0;
+                if (want) build_basis(h, b, b.chain_cap);
+            }
         }
         HIP_CHECK(hipDeviceSynchronize());
     } catch (const HipError& e) {

@@ -159,6 +159,22 @@ void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const S
                           const double* dmu, double* H);
 
 void launch_fill(hipStream_t st, double* p, int64_t n, double v);
+void launch_add(hipStream_t st, double* dst, const double* src, int64_t n);  // dst += src
+
+// Powers of A_k from the generator subspace: A_k = dt*sum_j ubar_j G_j lives in an (m+1)-dimensional
+// matrix space, so A_k^r = sum over multisets alpha of size r of (dt^r prod ubar_alpha) * S_alpha with
+// S_alpha = sum of the distinct orderings of the product G_alpha1 ... G_alphar, shared by all knots.
+// One GEMM  [vec(S_alpha)] (npad^2 x cnt) x coef (cnt x intervals)  then yields A_k^r for every
+// interval of the chunk -- 2*npad^2*cnt flops per interval instead of 2*npad^3.
+struct BasisSet {
+    int32_t r, cnt, cntpad;     // degree, number of multisets, padded to 16
+    const double* S;            // device [cntpad][npad^2]
+    const int32_t* idx;         // device [cnt][r] generator indices of each multiset
+    double* coef;               // device [capacity][cntpad] per-interval coefficients
+};
+void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const BasisSet& bs, const double* dZ,
+                       int64_t int0, int nb, int nbpad);
+void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out);
 // out2[0] = max_k min(b1_k, b2_k), out2[1] = max_k b1_k (bit patterns of non-negative doubles), where
 // b1_k >= ||A_k||_1 and b2_k >= ||A_k^2||_1^(1/2) follow from the generator norms g1[j] = ||G_j||_1,
 // n2[i][j] = ||G_i G_j||_1 and the triangle inequality.

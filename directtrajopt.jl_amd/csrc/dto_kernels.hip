@@ -51,6 +51,74 @@ void launch_fill(hipStream_t st, double* p, int64_t n, double v) {
     hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, st, p, n, v);
 }
 
+__global__ void k_add(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] += src[i];
+}
+void launch_add(hipStream_t st, double* dst, const double* src, int64_t n) {
+    if (n <= 0) return;
+    int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_add, dim3(grid), dim3(256), 0, st, dst, src, n);
+}
+
+// coef[b][alpha] = dt^r * prod_{i in alpha} ubar_i  (zero for padded intervals / padded multisets)
+__global__ void k_basis_coef(KProb P, KBil B, BasisSet bs, const double* __restrict__ Z, int64_t int0, int nb) {
+    const int b = blockIdx.x;
+    double* c = bs.coef + (int64_t)b * bs.cntpad;
+    if (b >= nb) {
+        for (int a = threadIdx.x; a < bs.cntpad; a += blockDim.x) c[a] = 0.0;
+        return;
+    }
+    const double* zk = Z + (int0 + b) * P.z;
+    const double dt = zk[P.dt_idx];
+    double dtr = dt;
+    for (int i = 1; i < bs.r; ++i) dtr *= dt;
+    for (int a = threadIdx.x; a < bs.cntpad; a += blockDim.x) {
+        double v = 0.0;
+        if (a < bs.cnt) {
+            v = dtr;
+            for (int i = 0; i < bs.r; ++i) {
+                const int g = bs.idx[a * bs.r + i];
+                if (g > 0) v *= zk[B.u_off + g - 1];
+            }
+        }
+        c[a] = v;
+    }
+}
+void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const BasisSet& bs, const double* dZ,
+                       int64_t int0, int nb, int nbpad) {
+    hipLaunchKernelGGL(k_basis_coef, dim3(nbpad), dim3(128), 0, st, P, B, bs, dZ, int0, nb);
+}
+
+// out[:, b] = S * coef[:, b]  for the nb intervals of the chunk (FP64 MFMA, same GEMM core).
+__global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSet bs, double* __restrict__ out) {
+    using Cfg = GemmCfg<128, 128>;
+    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
+    const int64_t nn = (int64_t)npad * npad;
+    const int row_tiles = (int)(nn / 128);
+    const int rt = blockIdx.x % row_tiles, ct = blockIdx.x / row_tiles;
+    GemmAcc<128, 128> acc;
+    acc.zero();
+    gemm_accumulate<128, 128>(acc, bs.S + (int64_t)rt * 128, (int)nn, bs.coef + (int64_t)ct * 128 * bs.cntpad, bs.cntpad,
+                              bs.cntpad, nullptr, smem);
+    GemmCoord<128, 128> co;
+    const int row0 = rt * 128 + co.row_base, col0 = ct * 128 + co.col_base;
+#pragma unroll
+    for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = col0 + 16 * tj + 4 * r;
+            if (col >= nb) continue;
+#pragma unroll
+            for (int ti = 0; ti < Cfg::MT; ++ti) out[(int64_t)col * nn + row0 + 16 * ti] = acc.v[ti][tj][r];
+        }
+}
+void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out) {
+    const int64_t nn = (int64_t)npad * npad;
+    hipLaunchKernelGGL(k_basis_gemm, dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(256), 0, st, npad, nb, bs, out);
+}
+
 __global__ void k_norm_bounds(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1,
                               const double* __restrict__ n2, unsigned long long* out2) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
