@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <string>
@@ -121,6 +122,8 @@ struct dto_handle {
     double* d_bounds = nullptr;  // [2] max beta, max b1 (as uint64 bit patterns)
     double* h_pinned = nullptr;  // [4]
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -140,6 +143,9 @@ dto_handle::~dto_handle() {
     for (void* p : owned) (void)hipFree(p);
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (stream) (void)hipStreamDestroy(stream);
+    if (stream2) (void)hipStreamDestroy(stream2);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
 }
 
 namespace {
@@ -258,7 +264,7 @@ void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool adjoint) {
     w.W = adjoint ? own(h, dalloc<double>(typesz * (b.k.m + 1))) : nullptr;
     w.scaleA = own(h, dalloc<double>((size_t)(b.k.m + 1) * w.Kpad));
     w.scaleU = own(h, dalloc<double>((size_t)(b.k.m + 1) * w.Kpad));
-    w.scaleE = own(h, dalloc<double>(w.Kpad));
+    w.scaleE = own(h, dalloc<double>((size_t)2 * w.Kpad));
     w.termnorm = own(h, dalloc<unsigned long long>((size_t)3 * T * w.Kpad));
     w.sumnorm = own(h, dalloc<unsigned long long>((size_t)T * w.Kpad));
     w.active = own(h, dalloc<int32_t>(w.Kpad / w.TN));
@@ -338,7 +344,7 @@ void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, con
         double segs = 0;
         for (int t = 0; t < ty.T; ++t) {
             segs += b.k.m + 1;
-            for (int e = 0; e < ty.t[t].n_extra; ++e) segs += ty.t[t].mult[e];
+            segs += ty.t[t].n_extra;
         }
         return 2.0 * b.k.npad * (double)b.k.npad * w.Kpad * segs;
     }();
@@ -446,7 +452,11 @@ int chunk_size(const dto_handle* h, int npad) {
 
 // exp(dt G(u_k)) for every owned interval; -E_k goes straight into the Jacobian slab.
 // Returns max_k ||A_k^2||_1^(1/2) (exact), which bounds the growth of the Taylor terms of the sweep.
-double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st) {
+// `after_last_enqueue(d2max)` runs on the host once every kernel of the chain has been enqueued (the GPU
+// is then busy with Horner products and squarings): the caller uses it to drive the generator sweep on a
+// second stream so that both proceed concurrently.
+double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st,
+                 const std::function<void(double)>& after_last_enqueue = nullptr) {
     const int npad = b.k.npad;
     const int64_t nint = h->P.n_int;
     double d2max = 0.0;
@@ -505,7 +515,46 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             src = src == 4 ? 5 : 4;
         }
     }
+    if (after_last_enqueue) after_last_enqueue(d2max);
     return d2max;
+}
+
+// max_k ||A_k^2||_1^(1/2), exact, for callbacks that do not run the propagator chain: A_k and A_k^2 only
+// (one streaming pass + one small GEMM per chunk).  Sharper than the generator-norm bound, so the sweep
+// usually needs a single round (q = 1).
+double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
+    const int npad = b.k.npad;
+    const int64_t nint = h->P.n_int;
+    double d2max = 0.0;
+    for (int64_t c0 = 0; c0 < nint; c0 += b.chain_cap) {
+        const int nb = (int)std::min<int64_t>(b.chain_cap, nint - c0);
+        const int64_t int0 = h->P.kn_lo + c0;
+        ChainWork& w = b.chain;
+        launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+        if (b.use_basis) {
+            const int nbpad = ((nb + 127) / 128) * 128;
+            launch_basis_coef(st, h->P, b.k, b.basis[0], dZ, int0, nb, nbpad);
+            launch_basis_gemm(st, npad, nb, nbpad, b.basis[0], w.W[1]);
+        } else {
+            launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]);
+        }
+        HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
+        launch_norm1_one(st, npad, nb, w, 1);
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
+        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        double dv;
+        memcpy(&dv, hs + 2, sizeof(double));
+        d2max = (dv == dv) ? std::max(d2max, dv) : dv;
+    }
+    return d2max;
+}
+
+SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
+    Bounds bd = get_bounds(h, b, dZ, st);
+    if (plan_sweep(bd.beta).q == 1) return plan_sweep(bd.beta);  // the cheap bound already gives one round
+    const double d2 = exact_d2(h, b, dZ, st);
+    return plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -525,8 +574,7 @@ void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st)
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
     for (auto& b : h->bil) {
         if (h->P.n_int > 0) {
-            Bounds bd = get_bounds(h, b, dZ, st);
-            SweepPlan plan = plan_sweep(bd.beta);
+            SweepPlan plan = plan_from(h, b, dZ, st);
             SweepTypes ty = make_types(0, false);
             run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
             launch_cons_bilinear(st, h->P, b.k, b.fw, dZ, dg);
@@ -543,13 +591,24 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
         Bounds bd{0, 0};
         if (h->P.n_int > 0) {
             bd = get_bounds(h, b, dZ, st);
-            const double d2 = run_chain(h, b, dZ, dvals, bd.b1, st);
-            // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
-            // (and still rigorous) growth rate for the sweep's step budget
-            SweepPlan plan = plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
-            SweepTypes ty = make_types(b.k.m, false);
-            run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
-            launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+            static const bool overlap = [] { const char* e = getenv("DTO_OVERLAP"); return e && atoi(e) != 0; }();  // off by default: +2% end to end, but per-kernel timings blur
+            hipStream_t ss = overlap ? h->stream2 : st;
+            if (overlap) {
+                HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
+                HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
+            }
+            run_chain(h, b, dZ, dvals, bd.b1, st, [&](double d2) {
+                // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
+                // (and still rigorous) growth rate for the sweep's step budget
+                SweepPlan plan = plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
+                SweepTypes ty = make_types(b.k.m, false);
+                run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss);
+                launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+            });
+            if (overlap) {
+                HIP_CHECK(hipEventRecord(h->ev_join, ss));
+                HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+            }
         }
         launch_jac_bilinear(st, h->P, b.k, b.fw, dvals);
     }
@@ -564,8 +623,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
         if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) {
             BilHost& b = h->bil[h->integ_index[i]];
             if (h->P.n_int <= 0) continue;
-            Bounds bd = get_bounds(h, b, dZ, st);
-            SweepPlan plan = plan_sweep(bd.beta);
+            SweepPlan plan = plan_from(h, b, dZ, st);
             SweepTypes ty2 = make_types(b.k.m, true);
             run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st);
             launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
@@ -662,6 +720,9 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         if (!sonly) {
             HIP_CHECK(hipSetDevice(h->device));
             HIP_CHECK(hipStreamCreate(&h->stream));
+            HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;

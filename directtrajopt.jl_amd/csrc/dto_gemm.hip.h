@@ -22,49 +22,56 @@ namespace dto {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int GEMM_KB = 16;
-constexpr int GEMM_THREADS = 256;
-
-template <int TM, int TN>
-struct GemmCfg {
-    static constexpr int KB = GEMM_KB;
-    static constexpr int LDA_S = TM + 16;
+// Shape of one workgroup-level GEMM: TM x TN tile, WR x WC wavefronts (64 lanes each), KB-deep K panel.
+template <int TM_, int TN_, int WR_ = 2, int WC_ = 2, int KB_ = 16>
+struct GemmShape {
+    static constexpr int TM = TM_, TN = TN_, WR = WR_, WC = WC_, KB = KB_;
+    static constexpr int THREADS = WR * WC * 64;
+    static constexpr int LDA_S = TM + 16;  // (TM+16) mod 32 == 16 for TM multiple of 32
     static constexpr int LDB_S = KB + 2;
     static constexpr int AS_ELEMS = KB * LDA_S;
     static constexpr int BS_ELEMS = TN * LDB_S;
     static constexpr int SMEM_DOUBLES = 2 * (AS_ELEMS + BS_ELEMS);
-    static constexpr int MT = TM / 32;  // accumulator tiles per wave along rows
-    static constexpr int NT = TN / 32;  // along columns
-    static constexpr int A_LD = (TM * KB / 2) / GEMM_THREADS;  // double2 loads per thread per panel
-    static constexpr int B_LD = (TN * KB / 2) / GEMM_THREADS;
+    static constexpr int WTM = TM / WR, WTN = TN / WC;  // per-wave tile
+    static constexpr int MT = WTM / 16;                 // accumulator tiles per wave along rows
+    static constexpr int NT = WTN / 16;                 // along columns
+    static constexpr int A_LD = (TM * KB / 2) / THREADS;  // double2 loads per thread per panel
+    static constexpr int B_LD = (TN * KB / 2) / THREADS;
+    static_assert(TM % (16 * WR) == 0 && TN % (16 * WC) == 0, "wave tile must be a multiple of 16");
+    static_assert((TM * KB / 2) % THREADS == 0 && (TN * KB / 2) % THREADS == 0, "panel loads must divide evenly");
+    static_assert(KB % 4 == 0, "K panel is a multiple of the MFMA depth");
 };
-
 template <int TM, int TN>
-struct GemmAcc {
-    d4 v[GemmCfg<TM, TN>::MT][GemmCfg<TM, TN>::NT];
+using GemmCfg = GemmShape<TM, TN, 2, 2, 16>;
+
+template <class S>
+struct GemmAccS {
+    d4 v[S::MT][S::NT];
     __device__ __forceinline__ void zero() {
 #pragma unroll
-        for (int i = 0; i < GemmCfg<TM, TN>::MT; ++i)
+        for (int i = 0; i < S::MT; ++i)
 #pragma unroll
-            for (int j = 0; j < GemmCfg<TM, TN>::NT; ++j) v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < S::NT; ++j) v[i][j] = d4{0.0, 0.0, 0.0, 0.0};
     }
 };
+template <int TM, int TN>
+using GemmAcc = GemmAccS<GemmCfg<TM, TN>>;
 
 // acc += A[0:TM, 0:Klen] * diag-scaled B[0:Klen, 0:TN]
 //   A      : pointer to the tile's first row, column 0 of the K range (column-major, lda)
 //   B      : pointer to row 0 of the K range, the tile's first column (column-major, ldb)
 //   colscale : nullptr, or TN per-column factors applied to B (b[k][n] *= colscale[n])
-//   Klen   : multiple of 16
-// All 256 threads must call it; it ends with a barrier so LDS may be reused immediately.
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const double* __restrict__ A,
-                                                int lda, const double* __restrict__ B, int ldb, int Klen,
-                                                const double* __restrict__ colscale, double* smem) {
-    using C = GemmCfg<TM, TN>;
+//   Klen   : multiple of KB
+// All threads of the workgroup must call it; it ends with a barrier so LDS may be reused immediately.
+template <class C>
+__device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double* __restrict__ A, int lda,
+                                                  const double* __restrict__ B, int ldb, int Klen,
+                                                  const double* __restrict__ colscale, double* smem) {
+    constexpr int TM = C::TM, TN = C::TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C::WC, wn = wave % C::WC;
     const int lr = lane & 15, lq = lane >> 4;
 
     double* As = smem;
@@ -75,13 +82,13 @@ __device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const doub
     double bsc[C::B_LD];
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
-        const int idx = tid + GEMM_THREADS * i;
+        const int idx = tid + C::THREADS * i;
         a_k[i] = idx / (TM / 2);
         a_m[i] = 2 * (idx % (TM / 2));
     }
 #pragma unroll
     for (int i = 0; i < C::B_LD; ++i) {
-        const int idx = tid + GEMM_THREADS * i;
+        const int idx = tid + C::THREADS * i;
         b_n[i] = idx / (C::KB / 2);
         b_k[i] = 2 * (idx % (C::KB / 2));
         bsc[i] = colscale ? colscale[b_n[i]] : 1.0;
@@ -120,8 +127,8 @@ __device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const doub
     for (int kb = 0; kb < nkb; ++kb) {
         const int buf = kb & 1;
         if (kb + 1 < nkb) load_panel(kb + 1);
-        const double* as = As + buf * C::AS_ELEMS + wm * (TM / 2) + lr;
-        const double* bs = Bs + buf * C::BS_ELEMS + (wn * (TN / 2) + lr) * C::LDB_S;
+        const double* as = As + buf * C::AS_ELEMS + wm * C::WTM + lr;
+        const double* bs = Bs + buf * C::BS_ELEMS + (wn * C::WTN + lr) * C::LDB_S;
 #pragma unroll
         for (int kk = 0; kk < C::KB; kk += 4) {
             double af[C::MT], bf[C::NT];
@@ -139,18 +146,26 @@ __device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const doub
         __syncthreads();
     }
 }
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const double* __restrict__ A, int lda,
+                                                const double* __restrict__ B, int ldb, int Klen,
+                                                const double* __restrict__ colscale, double* smem) {
+    gemm_accumulate_s<GemmCfg<TM, TN>>(acc, A, lda, B, ldb, Klen, colscale, smem);
+}
 
 // Coordinates of the calling lane's accumulator elements inside the TM x TN tile.
-template <int TM, int TN>
-struct GemmCoord {
+template <class S>
+struct GemmCoordS {
     int row_base;  // + 16*ti
     int col_base;  // + 16*tj + 4*r
-    __device__ __forceinline__ GemmCoord() {
+    __device__ __forceinline__ GemmCoordS() {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        row_base = (wave >> 1) * (TM / 2) + (lane & 15);
-        col_base = (wave & 1) * (TN / 2) + (lane >> 4);
+        row_base = (wave / S::WC) * S::WTM + (lane & 15);
+        col_base = (wave % S::WC) * S::WTN + (lane >> 4);
     }
 };
+template <int TM, int TN>
+using GemmCoord = GemmCoordS<GemmCfg<TM, TN>>;
 
 // XCD-aware decode of a 1-D grid into (batch, tile).  Workgroups b and b+8 share an XCD under the
 // observed round-robin dispatch, so the tiles of one matrix are given ids that differ by multiples

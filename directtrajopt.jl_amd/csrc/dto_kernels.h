@@ -89,6 +89,8 @@ struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices 
 void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, int64_t int0, int nb, double* A);
 void launch_bgemm_plain(hipStream_t st, int npad, int nb, const double* A, const double* Bm, double* C);
 void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w);
+// 1-norm of matrix `which` only; also folds max_k sqrt(norm) into w.d2max (used when the chain is not run)
+void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int which);
 void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w);
 void launch_poly_h3(hipStream_t st, int npad, int nb, const ChainWork& w);
 void launch_bgemm_horner(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int coef_base);
@@ -103,7 +105,7 @@ struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear i
     double* W;         // [(m+1)][Kpad][npad]  G_j' mu   (Hessian)
     double* scaleA;    // [(m+1)][Kpad]  dt*ubar_j/q
     double* scaleU;    // [(m+1)][Kpad]  ubar_j
-    double* scaleE;    // [Kpad]         dt/q
+    double* scaleE;    // [2][Kpad]      dt/q and 2*dt/q (the i == j second-order terms)
     unsigned long long* termnorm;  // [3][T][Kpad]
     unsigned long long* sumnorm;   // [T][Kpad]
     int32_t* active;   // [Kpad/TN]

@@ -218,15 +218,16 @@ struct BGemmArgs {
 // PERSISTENT: the grid is sized to the chip (2 workgroups per CU) and every workgroup walks the
 // (interval, tile) list with a stride of gridDim.x; this removes the workgroup re-dispatch gaps that a
 // one-tile-per-workgroup grid of ~8000 short workgroups shows (measured: 25 % of wall time).
-template <int T, int EPI>
-__global__ void __launch_bounds__(256, 2) k_bgemm(BGemmArgs a) {
-    using Cfg = GemmCfg<T, T>;
+template <class Cfg, int EPI>
+__global__ void __launch_bounds__(Cfg::THREADS, (Cfg::THREADS / 256) * (Cfg::SMEM_DOUBLES * 8 > 80 * 1024 ? 1 : 2))
+k_bgemm(BGemmArgs a) {
     __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
-    const int tiles_1d = a.npad / T;
-    const int tpm = tiles_1d * tiles_1d;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    const int tiles_r = a.npad / TM;
+    const int tpm = tiles_r * (a.npad / TN);
     const int total = batch_tile_count(a.nbatch, tpm);
     const int64_t nn = (int64_t)a.npad * a.npad;
-    GemmCoord<T, T> co;
+    GemmCoordS<Cfg> co;
     for (int v = blockIdx.x; v < total; v += gridDim.x) {
         int b, tile;
         if (!decode_batch_tile(v, a.nbatch, tpm, b, tile)) continue;
@@ -235,15 +236,15 @@ __global__ void __launch_bounds__(256, 2) k_bgemm(BGemmArgs a) {
             s_b = a.s[b];
             if (a.it >= s_b) continue;  // this interval needs no further squaring
         }
-        const int tr = tile % tiles_1d, tc = tile / tiles_1d;
-        const double* Ab = a.A + b * nn + (int64_t)tr * T;
-        const double* Bb = a.B + b * nn + (int64_t)tc * T * a.npad;
+        const int tr = tile % tiles_r, tc = tile / tiles_r;
+        const double* Ab = a.A + b * nn + (int64_t)tr * TM;
+        const double* Bb = a.B + b * nn + (int64_t)tc * TN * a.npad;
 
-        GemmAcc<T, T> acc;
+        GemmAccS<Cfg> acc;
         acc.zero();
-        gemm_accumulate<T, T>(acc, Ab, a.npad, Bb, a.npad, a.npad, nullptr, smem);
+        gemm_accumulate_s<Cfg>(acc, Ab, a.npad, Bb, a.npad, a.npad, nullptr, smem);
 
-        const int row0 = tr * T + co.row_base, col0 = tc * T + co.col_base;
+        const int row0 = tr * TM + co.row_base, col0 = tc * TN + co.col_base;
 
         if (EPI == EPI_SQUARE && a.it == s_b - 1) {
             // last squaring: the product is E_k; store -E_k into the Jacobian slab (x_k columns of the
@@ -300,20 +301,34 @@ static int bgemm_grid_cap() {
     static int v = [] { const char* e = getenv("DTO_BGEMM_WGS_PER_CU"); return e ? atoi(e) : 2; }();
     return v * 256;
 }
+static int bgemm_shape_choice() {
+    static int v = [] { const char* e = getenv("DTO_BGEMM_SHAPE"); return e ? atoi(e) : -1; }();
+    return v;
+}
+template <class Cfg, int EPI>
+static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_cu) {
+    int grid = batch_tile_count(a.nbatch, (a.npad / Cfg::TM) * (a.npad / Cfg::TN));
+    const int cap = bgemm_grid_cap() > 0 ? wgs_per_cu * 256 : 0;
+    if (cap > 0 && grid > cap) grid = cap;
+    hipLaunchKernelGGL((k_bgemm<Cfg, EPI>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+}
 template <int EPI>
 static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
-    const int cap = bgemm_grid_cap();
-    if (a.npad % 128 == 0) {
-        const int t1 = a.npad / 128;
-        int grid = batch_tile_count(a.nbatch, t1 * t1);
-        if (cap > 0 && grid > cap) grid = cap;
-        hipLaunchKernelGGL((k_bgemm<128, EPI>), dim3(grid), dim3(256), 0, st, a);
+    if (a.npad % 256 == 0) {
+        // shapes measured with tools/bgemm_probe2 (256x2000): see DESIGN.md
+        switch (bgemm_shape_choice()) {
+            case 0: launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2); return;
+            case 1: launch_bgemm_shape<GemmShape<128, 128, 2, 2, 8>, EPI>(st, a, 2); return;
+            case 2: launch_bgemm_shape<GemmShape<256, 128, 4, 2, 16>, EPI>(st, a, 1); return;
+            case 3: launch_bgemm_shape<GemmShape<256, 128, 4, 2, 8>, EPI>(st, a, 1); return;
+            case 4: launch_bgemm_shape<GemmShape<128, 256, 2, 4, 16>, EPI>(st, a, 1); return;
+            case 5: launch_bgemm_shape<GemmShape<128, 256, 2, 4, 8>, EPI>(st, a, 1); return;
+            default: launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2); return;
+        }
+    } else if (a.npad % 128 == 0) {
+        launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
     } else {
-        const int t1 = a.npad / 64;
-        int grid = batch_tile_count(a.nbatch, t1 * t1);
-        const int cap64 = cap * 2;  // 64x64 tiles: 4 workgroups per CU fit
-        if (cap > 0 && grid > cap64) grid = cap64;
-        hipLaunchKernelGGL((k_bgemm<64, EPI>), dim3(grid), dim3(256), 0, st, a);
+        launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
     }
 }
 
@@ -337,8 +352,8 @@ void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, i
 }
 
 // 1-norms (max column abs sum) of A, A^2, A^3, A^4 per interval: exact inputs of the scaling choice.
-__global__ void __launch_bounds__(256) k_norm1(int npad, ChainWork w) {
-    const int b = blockIdx.x, which = blockIdx.y;
+__global__ void __launch_bounds__(256) k_norm1(int npad, ChainWork w, int only) {
+    const int b = blockIdx.x, which = only >= 0 ? only : blockIdx.y;
     const double* M = w.W[which] + (int64_t)b * npad * npad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double best = 0.0;
@@ -351,10 +366,17 @@ __global__ void __launch_bounds__(256) k_norm1(int npad, ChainWork w) {
     __shared__ double sm[4];
     if (lane == 0) sm[wave] = best;
     __syncthreads();
-    if (threadIdx.x == 0) w.norms[b * 4 + which] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    if (threadIdx.x == 0) {
+        const double nrm = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        w.norms[b * 4 + which] = nrm;
+        if (only == 1) atomicMax(w.d2max, dbits(sqrt(nrm)));
+    }
 }
 void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w) {
-    hipLaunchKernelGGL(k_norm1, dim3(nb, 4), dim3(256), 0, st, npad, w);
+    hipLaunchKernelGGL(k_norm1, dim3(nb, 4), dim3(256), 0, st, npad, w, -1);
+}
+void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int which) {
+    hipLaunchKernelGGL(k_norm1, dim3(nb, 1), dim3(256), 0, st, npad, w, which);
 }
 
 // Scaling parameter s_k and the scaled Taylor coefficients sigma^i / i!  (sigma = 2^-s_k).
@@ -453,6 +475,7 @@ __global__ void __launch_bounds__(256) k_sweep_init(KProb P, KBil B, SweepBuf w,
         }
         const double dt = live ? Z[kn * P.z + P.dt_idx] : 0.0;
         w.scaleE[k] = dt * inv_q;
+        w.scaleE[w.Kpad + k] = 2.0 * dt * inv_q;
         for (int j = 0; j <= B.m; ++j) {
             const double ub = live ? (j == 0 ? 1.0 : Z[kn * P.z + B.u_off + j - 1]) : 0.0;
             w.scaleU[(int64_t)j * w.Kpad + k] = ub;
@@ -536,13 +559,9 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {
         const TypeDesc td = a.ty.t[ty];
         for (int e = 0; e < td.n_extra; ++e) {
             const double* Bs = a.Zin + td.src[e] * typesz + (int64_t)ct * TN * npad;
-            // mult is folded in by running the segment `mult` times would be wasteful: scaleE carries
-            // dt/q and mult is applied through a second pass only when it is 2 (i == j terms).
+            // scaleE[0] carries dt/q, scaleE[1] carries 2 dt/q (the i == j second-order terms)
             gemm_accumulate<TM, TN>(acc, a.G + (int64_t)td.gen[e] * nn + (int64_t)rt * TM, npad, Bs, npad, npad,
-                                    a.w.scaleE + ct * TN, smem);
-            if (td.mult[e] == 2.0)
-                gemm_accumulate<TM, TN>(acc, a.G + (int64_t)td.gen[e] * nn + (int64_t)rt * TM, npad, Bs, npad, npad,
-                                        a.w.scaleE + ct * TN, smem);
+                                    a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
         }
     } else if (a.mode == 1) {
         gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
