@@ -842,6 +842,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         }
         for (auto& c : h->con) {
             std::vector<int64_t> times, lrows, tidx, jpos;
+            std::vector<int32_t> hess_on;
             for (int64_t i = 0; i < c.n_times_total; ++i) {
                 const int64_t kn = c.times0[i];
                 if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
@@ -853,6 +854,12 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 times.push_back(kn);
                 lrows.push_back(lrow++);
                 tidx.push_back(i);
+                {
+                    int32_t last = 1;
+                    for (int64_t i2 = i + 1; i2 < c.n_times_total; ++i2)
+                        if (c.times0[i2] == kn) { last = 0; break; }
+                    hess_on.push_back(last);
+                }
                 for (size_t q = 0; q < c.comps.size(); ++q) {
                     const int64_t col = kn * h->z + c.comps[q];
                     int64_t pos = -1;
@@ -872,6 +879,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 c.k.times = own(h, dupload(times));
                 c.k.lrow = own(h, dupload(lrows));
                 c.k.tidx = own(h, dupload(tidx));
+                c.k.hess_on = own(h, dupload(hess_on));
                 c.k.jpos = own(h, dupload(jpos));
             }
         }

@@ -140,6 +140,8 @@ struct KCon {  // NonlinearKnotPointConstraint with a built-in g
     int64_t n_times;
     int64_t mu_off;          // global 0-based row of the constraint's first row (for mu), evaluator.jl:219-223
     const int64_t* tidx;     // device, index of each owned time inside the constraint's full `times`
+    const int32_t* hess_on;  // device, 0 where a LATER entry of `times` names the same knot: the reference's
+                             // ForwardDiff.hessian! into the block view overwrites (knot_point_constraint.jl:285-291)
 };
 void launch_cons_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* g);
 void launch_jac_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* vals);

@@ -983,6 +983,7 @@ __global__ void k_hess_knot(KProb P, KCon C, const double* __restrict__ Z, const
     const int nc2 = C.n_comps * C.n_comps;
     if (i >= C.n_times * nc2) return;
     const int64_t ti = i / nc2;
+    if (!C.hess_on[ti]) return;
     const int a = (int)((i % nc2) / C.n_comps), b = (int)(i % C.n_comps);
     const int ca = C.comps[a], cb = C.comps[b];
     if (ca > cb) return;

@@ -1,0 +1,127 @@
+"""GPU parity on the edge cases of the path: term variety (LinearRegularizer, baselines, time subsets,
+weights, sqnorm / equality constraints, duplicate constraint times), component orders that drop the
+(v,dt) Hessian cross terms, global variables, several bilinear integrators, zero-drive problems,
+minimum sizes, non-finite iterates."""
+import numpy as np
+import pytest
+
+import dto_oracle as O
+from helpers import rel_err, run_all, to_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(p, Z=None, hessian=True, tol=1e-10, tol_h=1e-8):
+    import dto_amd
+    ev_o = O.OracleEvaluator(p)
+    ev = dto_amd.Evaluator(to_engine(p), eval_hessian=hessian)
+    try:
+        r, c = ev.jacobian_structure(); r1, c1 = ev_o.jacobian_structure1()
+        assert np.array_equal(r, r1) and np.array_equal(c, c1)
+        r, c = ev.hessian_lagrangian_structure(); r1, c1 = ev_o.hessian_structure1()
+        assert np.array_equal(r, r1) and np.array_equal(c, c1)
+        Z = p.Z0.copy() if Z is None else Z
+        mu = np.random.default_rng(7).standard_normal(ev_o.n_constraints)
+        out = run_all(ev, p, Z, mu, sigma=1.3, hessian=hessian)
+        assert rel_err(out["f"], ev_o.eval_objective(Z)) <= tol
+        assert rel_err(out["grad"], ev_o.eval_objective_gradient(Z)) <= tol
+        assert rel_err(out["cons"], ev_o.eval_constraint(Z)) <= tol
+        assert rel_err(out["jac"], ev_o.eval_constraint_jacobian(Z)) <= tol
+        if hessian:
+            assert rel_err(out["hess"], ev_o.eval_hessian_lagrangian(Z, 1.3, mu)) <= tol_h
+        return out
+    finally:
+        ev.close()
+
+
+def test_objective_term_variety():
+    N, n, m = 7, 5, 2
+    p = O.make_scaled_problem(N, n, m, seed=31)
+    rng = np.random.default_rng(0)
+    p.objectives = [
+        O.QuadraticRegularizer(n, m, np.array([0.5, 2.0]), baseline=rng.standard_normal((m, N)), times1=[1, 3, 4, 7]),
+        O.LinearRegularizer(n + m, m, np.array([1e-2, 3e-2])),
+        O.MinimumTimeObjective(2.5),
+        O.QuadraticRegularizer(0, n, rng.random(n)),
+    ]
+    p.weights = [1.0, 0.3, 2.0, 0.1]
+    _compare(p)
+
+
+def test_constraint_kinds_equality_and_duplicate_times():
+    N, n, m = 6, 4, 2
+    p = O.make_scaled_problem(N, n, m, seed=8)
+    p.constraints = [
+        O.KnotConstraint("norm", [n, n + 1], 1.0, [2, 3, 3, 5], equality=False),   # a knot listed twice
+        O.KnotConstraint("sqnorm", [0, 1, 2], 0.5, [1, N], equality=True),
+        O.KnotConstraint("norm", [n + m, n + m + 1, n], 2.0, [4], equality=False),  # unordered comps
+    ]
+    _compare(p)
+
+
+def test_timestep_before_regularized_component_drops_cross_terms():
+    """(v,dt) Hessian entries of the regularizers survive only if dt follows v (regularizers.jl:160,
+    evaluator.jl:637): here dt is the FIRST component."""
+    N, n, m = 5, 3, 2
+    rng = np.random.default_rng(3)
+    z = 1 + n + 2 * m
+    data = np.vstack([0.1 + 0.05 * rng.random((1, N)), rng.standard_normal((n, N)), 0.2 * rng.standard_normal((m, N)),
+                      rng.standard_normal((m, N))])
+    G = rng.standard_normal((m + 1, n, n))
+    p = O.Problem(N=N, z=z, dt_idx=0,
+                  integrators=[O.DerivativeIntegrator(1 + n, m, 1 + n + m), O.BilinearIntegrator(1, n, 1 + n, m, G)],
+                  objectives=[O.QuadraticRegularizer(1 + n, m, np.ones(m)), O.LinearRegularizer(1 + n + m, m, np.ones(m))],
+                  Z0=data.T.reshape(-1).copy())
+    _compare(p)
+
+
+def test_two_bilinear_integrators_and_global_columns():
+    N = 5
+    rng = np.random.default_rng(11)
+    # comps: x[3], y[2], u[2], dt ; globals: 3 (no hot-path term touches them, columns still exist)
+    data = np.vstack([rng.standard_normal((3, N)), rng.standard_normal((2, N)), 0.3 * rng.standard_normal((2, N)),
+                      np.full((1, N), 0.15)])
+    p = O.Problem(N=N, z=8, dt_idx=7, gd=3,
+                  integrators=[O.BilinearIntegrator(0, 3, 5, 2, rng.standard_normal((3, 3, 3))),
+                               O.BilinearIntegrator(3, 2, 5, 2, rng.standard_normal((3, 2, 2)))],
+                  objectives=[O.QuadraticRegularizer(5, 2, np.ones(2))],
+                  Z0=np.concatenate([data.T.reshape(-1), rng.standard_normal(3)]))
+    _compare(p)
+
+
+def test_minimum_sizes():
+    rng = np.random.default_rng(2)
+    data = np.vstack([rng.standard_normal((1, 2)), rng.standard_normal((1, 2)), np.full((1, 2), 0.2)])
+    p = O.Problem(N=2, z=3, dt_idx=2, integrators=[O.BilinearIntegrator(0, 1, 1, 1, rng.standard_normal((2, 1, 1)))],
+                  objectives=[], Z0=data.T.reshape(-1).copy())
+    _compare(p)
+
+
+def test_zero_controls_and_zero_state():
+    p = O.make_scaled_problem(5, 6, 2, seed=4)
+    Z = p.Z0.copy()
+    Z[6:8] = 0.0             # u = 0 at knot 1: A = dt G0
+    Z[p.z:p.z + 6] = 0.0     # x = 0 at knot 2: every sweep column of that interval is zero
+    _compare(p, Z=Z)
+
+
+def test_wide_range_of_norms_in_one_call():
+    """Per-interval scaling: dt spans 1e-6 .. 2, so s_k ranges from 1 to many squarings in one launch."""
+    p = O.make_scaled_problem(8, 12, 2, seed=17)
+    Z = p.Z0.copy()
+    Z[p.dt_idx::p.z] = [1e-6, 1e-3, 0.05, 0.3, 0.8, 1.5, 2.0, 0.1]
+    _compare(p, Z=Z, tol=1e-9, tol_h=1e-7)  # ||exp|| grows to ~1e6 here: tolerance relative to max(1,|ref|)
+
+
+def test_non_finite_iterate_propagates_without_error():
+    """Solvers may probe non-finite points; the reference would return NaNs, not throw."""
+    import dto_amd
+    p = O.make_scaled_problem(4, 4, 2, seed=1)
+    ev = dto_amd.Evaluator(to_engine(p))
+    Z = p.Z0.copy()
+    Z[p.z + 1] = np.nan  # a state entry of knot 2
+    g = np.zeros(ev.n_constraints); ev.eval_constraint(g, Z)
+    j = np.zeros(ev.n_jacobian_entries); ev.eval_constraint_jacobian(j, Z)
+    assert np.isnan(g).any() and np.isfinite(g[-2:]).all()
+    assert np.isfinite(j[:p.z]).any()
+    ev.close()

@@ -1,0 +1,27 @@
+import sys, time, json
+sys.path.insert(0,'/root/repo')
+import numpy as np, torch, dto_amd
+def run(n, m, N, cb="jacobian", steps=3):
+    prob = dto_amd.host.synthetic.make_scaled_problem(N, n, m, seed=42)
+    ev = dto_amd.Evaluator(prob, eval_hessian=(cb=="hessian"))
+    dev = torch.device("cuda",0)
+    Z = torch.from_numpy(prob.trajectory.vec()).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if cb=="jacobian":
+        out = torch.empty(ev.shard.jac_len, dtype=torch.float64, device=dev); f = lambda: ev.eval_jacobian_dev(Z.data_ptr(), out.data_ptr(), st)
+    elif cb=="hessian":
+        out = torch.empty(ev.shard.hess_len, dtype=torch.float64, device=dev); mu = torch.ones(ev.n_constraints, dtype=torch.float64, device=dev)
+        f = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), out.data_ptr(), st)
+    else:
+        out = torch.empty(ev.shard.cons_len, dtype=torch.float64, device=dev); f = lambda: ev.eval_constraint_dev(Z.data_ptr(), out.data_ptr(), st)
+    f(); torch.cuda.synchronize()
+    t0=time.perf_counter()
+    for _ in range(steps): f()
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/steps
+    print(f"n={n} m={m} N={N} {cb}: {dt*1e3:.3f} ms  {N/dt:.0f} knot-points/s finite={bool(torch.isfinite(out).all())} stats={ev.last_stats()}", flush=True)
+    ev.close()
+for cb in ("constraint","jacobian","hessian"):
+    run(64, 4, 1000, cb)
+for cb in ("constraint","jacobian","hessian"):
+    run(1024, 4, 128, cb, steps=2)
+run(4, 2, 51, "jacobian"); run(4, 2, 51, "hessian")
