@@ -323,10 +323,13 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
             case 3: launch_bgemm_shape<GemmShape<256, 128, 4, 2, 8>, EPI>(st, a, 1); return;
             case 4: launch_bgemm_shape<GemmShape<128, 256, 2, 4, 16>, EPI>(st, a, 1); return;
             case 5: launch_bgemm_shape<GemmShape<128, 256, 2, 4, 8>, EPI>(st, a, 1); return;
-            default: launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2); return;
+            case 6: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2); return;
+            case 7: launch_bgemm_shape<GemmShape<128, 128, 4, 2, 16>, EPI>(st, a, 2); return;
+            case 8: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 8>, EPI>(st, a, 3); return;
+            default: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2); return;  // 8 waves: +6 % in the engine
         }
     } else if (a.npad % 128 == 0) {
-        launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
+        launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
     } else {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
     }
@@ -536,7 +539,7 @@ struct SweepArgs {
 // i.e. a GEMM whose K dimension is the concatenation of the generator blocks, the per-interval
 // bilinear coefficients being applied to the B panel while it is staged into LDS.
 template <int TM, int TN>
-__global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {
+__global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(SweepArgs a) {
     using Cfg = GemmCfg<TM, TN>;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
     const int npad = a.w.npad, Kpad = a.w.Kpad;
@@ -627,7 +630,7 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
     const int npad = a.w.npad;
     // tile choice: enough workgroups to cover 256 CUs a few times over (the per-step GEMM is small)
     int choice = sweep_tile_choice();
-    if (choice < 0) choice = 0;  // 64x64 measured fastest at 256x2000 (2.5 workgroups per CU)
+    if (choice < 0) choice = 5;  // 64x32 measured fastest at 256x2000 (1280 workgroups = 5 per CU: balanced)
     if (npad % 128 != 0 || a.w.TN != 128) choice = 0;
     switch (choice) {
         case 3:
@@ -638,6 +641,12 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
             break;
         case 1:
             hipLaunchKernelGGL((k_sweep<128, 64>), dim3((npad / 128) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
+            break;
+        case 4:
+            hipLaunchKernelGGL((k_sweep<32, 64>), dim3((npad / 32) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
+            break;
+        case 5:
+            hipLaunchKernelGGL((k_sweep<64, 32>), dim3((npad / 64) * (a.w.Kpad / 32), ny), dim3(256), 0, st, a);
             break;
         default:
             hipLaunchKernelGGL((k_sweep<64, 64>), dim3((npad / 64) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
