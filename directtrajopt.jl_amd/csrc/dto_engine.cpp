@@ -120,6 +120,10 @@ struct dto_handle {
     double* d_partial = nullptr;
     double* d_f = nullptr;
     double* d_bounds = nullptr;  // [2] max beta, max b1 (as uint64 bit patterns)
+    double* d_jac_scratch = nullptr;     // value slab for the Jacobian-vector products (lazy)
+    double* d_w = nullptr;               // product input
+    int64_t* d_conbase = nullptr;        // [n_vars+1] first constraint-pattern entry of each column
+    int64_t* d_con_rows = nullptr;       // constraint-pattern rows, (col,row) order
     double* h_pinned = nullptr;  // [4]
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
@@ -1142,11 +1146,40 @@ int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double*
     });
 }
 
-int dto_eval_jacobian_product(dto_handle* h, const double*, const double*, double*) {
-    return fail(h, "dto_eval_jacobian_product: not implemented yet (SURVEY.md §8f rank 1)");
+static void jac_product(dto_handle* h, const double* Z, const double* w, double* y, int transpose) {
+    if (h->k_lo != 1 || h->k_hi != h->N) throw HipError{"Jacobian-vector products need an unsharded handle"};
+    if (h->integ_kind.size() > 8) throw HipError{"Jacobian-vector products support at most 8 integrators"};
+    const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;
+    if (!h->d_jac_scratch) {
+        h->d_jac_scratch = own(h, dalloc<double>((size_t)h->info.jac_len));
+        h->d_w = own(h, dalloc<double>((size_t)std::max(h->n_vars, h->n_cons)));
+        std::vector<int64_t> base((size_t)h->n_vars + 1, 0);
+        for (size_t e = 0; e < h->con_cols.size(); ++e) base[(size_t)h->con_cols[e] + 1]++;
+        for (int64_t c = 0; c < h->n_vars; ++c) base[(size_t)c + 1] += base[(size_t)c];
+        h->d_conbase = own(h, dupload(base));
+        h->d_con_rows = own(h, dupload(h->con_rows));
+    }
+    KIntegTable T{};
+    T.n = (int)h->integ_kind.size();
+    for (int i = 0; i < T.n; ++i) { T.d[i] = h->integ_dim[i]; T.off[i] = h->integ_row_off[i]; }
+    upload_Z(h, Z);
+    HIP_CHECK(hipMemcpyAsync(h->d_w, w, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, h->stream));
+    do_jacobian(h, h->d_Z, h->d_jac_scratch, h->stream);
+    double* o = staging(h, (size_t)n_out);
+    HIP_CHECK(hipMemsetAsync(o, 0, sizeof(double) * (size_t)n_out, h->stream));  // fill!(y, 0), evaluator.jl:416,442
+    if (T.n > 0 || !h->con.empty())
+        launch_jac_spmv(h->stream, h->P, T, h->d_conbase, h->d_con_rows, h->d_jac_scratch, h->d_w, o, transpose);
+    HIP_CHECK(hipMemcpyAsync(y, o, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    check_sweeps(h);
 }
-int dto_eval_jacobian_transpose_product(dto_handle* h, const double*, const double*, double*) {
-    return fail(h, "dto_eval_jacobian_transpose_product: not implemented yet (SURVEY.md §8f rank 1)");
+// y = J(Z) w  -- MOI.eval_constraint_jacobian_product (evaluator.jl:406-430)
+int dto_eval_jacobian_product(dto_handle* h, const double* Z, const double* w, double* y) {
+    return guarded(h, [&] { jac_product(h, Z, w, y, 0); });
+}
+// y = J(Z)' w -- MOI.eval_constraint_jacobian_transpose_product (evaluator.jl:432-456)
+int dto_eval_jacobian_transpose_product(dto_handle* h, const double* Z, const double* w, double* y) {
+    return guarded(h, [&] { jac_product(h, Z, w, y, 1); });
 }
 
 // ---- measurement

@@ -163,6 +163,16 @@ void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const S
                           const double* dmu, double* H);
 
 void launch_fill(hipStream_t st, double* p, int64_t n, double v);
+
+// y = J w / y = J' w from the value slab in CSC order (A3: evaluator.jl:406-456; the reference also
+// materialises the Jacobian values first, on the host).  One wavefront per column.
+struct KIntegTable {
+    int32_t n;
+    int32_t d[8];
+    int64_t off[8];
+};
+void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
+                     const double* vals, const double* w, double* y, int transpose);
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n);  // dst += src
 
 // Powers of A_k from the generator subspace: A_k = dt*sum_j ubar_j G_j lives in an (m+1)-dimensional

@@ -119,6 +119,51 @@ void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisS
     hipLaunchKernelGGL(k_basis_gemm, dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(256), 0, st, npad, nb, bs, out);
 }
 
+// One wavefront per column c of the owned knots: walk the column's entries in the structure's order
+// (per integrator: rows of interval k-1 then of interval k; then the constraint rows).
+template <int TRANSPOSE>
+__global__ void __launch_bounds__(64) k_jac_spmv(KProb P, KIntegTable T, const int64_t* __restrict__ conbase,
+                                                 const int64_t* __restrict__ con_rows, const double* __restrict__ vals,
+                                                 const double* __restrict__ w, double* __restrict__ y) {
+    const int64_t cl = blockIdx.x;                 // local column
+    const int64_t c = P.kn_lo * P.z + cl;          // global column
+    const int64_t kn = c / P.z;
+    const int has_prev = kn >= 1, has_own = kn < P.K;
+    const int cnt = has_prev + has_own;
+    const int64_t e0 = P.colptr[c], e1 = P.colptr[c + 1];
+    const int64_t Lint = (int64_t)P.D * cnt;
+    const double wc = TRANSPOSE ? 0.0 : w[c];
+    double acc = 0.0;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 64) {
+        const int64_t el = e - e0;
+        int64_t row;
+        if (el < Lint) {
+            int64_t rem = el;
+            int i = 0;
+            while (i < T.n - 1 && rem >= (int64_t)T.d[i] * cnt) { rem -= (int64_t)T.d[i] * cnt; ++i; }
+            const int d = T.d[i];
+            if (has_prev && rem < d) row = T.off[i] + (kn - 1) * d + rem;
+            else row = T.off[i] + kn * d + (rem - (has_prev ? d : 0));
+        } else {
+            row = con_rows[conbase[c] + (el - Lint)];
+        }
+        const double v = vals[e - P.jac_lo];
+        if (TRANSPOSE) acc += v * w[row];
+        else if (v != 0.0) atomicAdd(&y[row], v * wc);
+    }
+    if (TRANSPOSE) {
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) y[c] = acc;
+    }
+}
+void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
+                     const double* vals, const double* w, double* y, int transpose) {
+    const int64_t ncols = P.n_knots * P.z;
+    if (ncols <= 0) return;
+    if (transpose) hipLaunchKernelGGL(k_jac_spmv<1>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
+    else hipLaunchKernelGGL(k_jac_spmv<0>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
+}
+
 __global__ void k_norm_bounds(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1,
                               const double* __restrict__ n2, unsigned long long* out2) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -186,6 +186,16 @@ class Evaluator:
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         self._check(self._lib.dto_eval_hessian(self._h, _dp(Z), float(sigma), _dp(mu), _dp(H)))
 
+    def eval_constraint_jacobian_product(self, y, Z, w):  # evaluator.jl:406 (y = J w)
+        Z = self._Z(Z)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        self._check(self._lib.dto_eval_jacobian_product(self._h, _dp(Z), _dp(w), _dp(y)))
+
+    def eval_constraint_jacobian_transpose_product(self, y, Z, w):  # evaluator.jl:432 (y = J' w)
+        Z = self._Z(Z)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        self._check(self._lib.dto_eval_jacobian_transpose_product(self._h, _dp(Z), _dp(w), _dp(y)))
+
     def constraint_bounds(self):  # get_nonlinear_constraints, src/solvers/solve.jl:30-65
         lo = np.empty(self.n_constraints)
         hi = np.empty(self.n_constraints)

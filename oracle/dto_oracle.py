@@ -605,6 +605,18 @@ class OracleEvaluator:
             scatter(objective_full_hessian(self.prob, Z), sigma)
         return out
 
+    def eval_constraint_jacobian_product(self, Z, w):
+        """MOI.eval_constraint_jacobian_product -- evaluator.jl:406-430 (materialise, then y[row] += w[col]*v)."""
+        y = np.zeros(self.n_constraints)
+        np.add.at(y, self.jac_rows, w[self.jac_cols] * self.eval_constraint_jacobian(Z))
+        return y
+
+    def eval_constraint_jacobian_transpose_product(self, Z, w):
+        """MOI.eval_constraint_jacobian_transpose_product -- evaluator.jl:432-456."""
+        y = np.zeros(self.prob.n_vars)
+        np.add.at(y, self.jac_cols, w[self.jac_rows] * self.eval_constraint_jacobian(Z))
+        return y
+
     def row_bounds(self):
         """get_nonlinear_constraints -- src/solvers/solve.jl:30-65."""
         lo = np.zeros(self.n_constraints)

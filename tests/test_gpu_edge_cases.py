@@ -125,3 +125,20 @@ def test_non_finite_iterate_propagates_without_error():
     assert np.isnan(g).any() and np.isfinite(g[-2:]).all()
     assert np.isfinite(j[:p.z]).any()
     ev.close()
+
+
+def test_jacobian_vector_products():
+    """A3: y = J w and y = J' w (evaluator.jl:406-456; the reference compares them with the dense J,
+    evaluator.jl:808-853)."""
+    import dto_amd
+    for p in (O.make_standard_problem(N=7), O.make_scaled_problem(6, 9, 3, seed=23, with_constraint=True)):
+        ev_o = O.OracleEvaluator(p)
+        ev = dto_amd.Evaluator(to_engine(p))
+        rng = np.random.default_rng(5)
+        w = rng.standard_normal(p.n_vars)
+        v = rng.standard_normal(ev_o.n_constraints)
+        y = np.full(ev_o.n_constraints, np.nan); ev.eval_constraint_jacobian_product(y, p.Z0, w)
+        yt = np.full(p.n_vars, np.nan); ev.eval_constraint_jacobian_transpose_product(yt, p.Z0, v)
+        assert rel_err(y, ev_o.eval_constraint_jacobian_product(p.Z0, w)) <= 1e-10
+        assert rel_err(yt, ev_o.eval_constraint_jacobian_transpose_product(p.Z0, v)) <= 1e-10
+        ev.close()
