@@ -68,6 +68,7 @@ struct BilHost {
     int chain_cap = 0;
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
     BasisSet basis[3]{};      // degrees 2, 3, 4
+    BasisSet basis_all{};     // every multiset of degree 0..4: one GEMM gives the bracket H3
 };
 
 struct ConHost {
@@ -426,6 +427,33 @@ void build_basis(dto_handle* h, BilHost& b, int cap) {
         const int cappad = ((cap + 127) / 128) * 128;
         bs.coef = own(h, dalloc<double>((size_t)cappad * cntpad));
     }
+    {
+        // concatenation [I | G_0..G_m | S2 | S3 | S4] for the H3 bracket
+        int cnt = 1 + m1;
+        for (int r = 2; r <= 4; ++r) cnt += (int)sets[r].size();
+        const int cntpad = ((cnt + 15) / 16) * 16;
+        double* Sall = own(h, dalloc<double>(nn * cntpad));
+        HIP_CHECK(hipMemsetAsync(Sall, 0, nn * cntpad * sizeof(double), h->stream));
+        std::vector<double> eye(nn, 0.0);
+        for (int i = 0; i < b.k.n; ++i) eye[(size_t)i * npad + i] = 1.0;  // identity on the un-padded block only
+        HIP_CHECK(hipMemcpyAsync(Sall, eye.data(), nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        std::vector<int32_t> idx;
+        size_t col = 1;
+        for (int q = 0; q < 4; ++q) idx.push_back(-1);
+        for (int r = 1; r <= 4; ++r) {
+            HIP_CHECK(hipMemcpyAsync(Sall + col * nn, S[r], nn * sets[r].size() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            col += sets[r].size();
+            for (auto& al : sets[r]) {
+                for (int q = 0; q < 4; ++q) idx.push_back(q < r ? al[q] : -1);
+            }
+        }
+        BasisSet& bs = b.basis_all;
+        bs.r = 4; bs.cnt = cnt; bs.cntpad = cntpad; bs.S = Sall;
+        bs.idx = own(h, dupload(idx));
+        const int cappad = ((cap + 127) / 128) * 128;
+        bs.coef = own(h, dalloc<double>((size_t)cappad * cntpad));
+    }
     HIP_CHECK(hipStreamSynchronize(h->stream));
     b.use_basis = true;
 }
@@ -434,6 +462,7 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     const size_t nn = (size_t)b.k.npad * b.k.npad;
     for (int i = 0; i < 6; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
     b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
+    b.chain.colsum = own(h, dalloc<double>((size_t)3 * cap * b.k.npad));
     b.chain.coef = own(h, dalloc<double>((size_t)cap * COEF_STRIDE));
     b.chain.s = own(h, dalloc<int32_t>(cap));
     b.chain.smax = own(h, dalloc<int32_t>(4));
@@ -478,17 +507,23 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
         if (b.use_basis) {
             const int nbpad = ((nb + 127) / 128) * 128;
+            HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * (size_t)3 * cap * npad, st));
+            launch_fill(st, w.norms, (int64_t)nb * 4, INFINITY);  // ||A||_1 is not needed: alpha never exceeds d_2
             for (int r = 0; r < 3; ++r) {
-                launch_basis_coef(st, h->P, b.k, b.basis[r], dZ, int0, nb, nbpad);
-                ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis[r].cntpad * nb);
-                launch_basis_gemm(st, npad, nb, nbpad, b.basis[r], w.W[1 + r]);
+                launch_basis_coef(st, h->P, b.k, b.basis[r], dZ, int0, nb, nbpad, nullptr);
+                double* cs = w.colsum + (size_t)r * cap * npad;
+                {
+                    ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis[r].cntpad * nb);
+                    launch_basis_gemm(st, npad, nb, nbpad, b.basis[r], w.W[1 + r], cs);
+                }
+                launch_norm_from_colsum(st, npad, nb, cs, w.norms, 1 + r);
             }
         } else {
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
         }
-        launch_norm1(st, npad, nb, w);
+        if (!b.use_basis) launch_norm1(st, npad, nb, w);
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
         launch_expm_params(st, nb, s_ub, w);
         // the number of squaring launches is data dependent: read back max/sum of s_k (8 bytes) while
@@ -498,7 +533,14 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         hipEvent_t ev_s;
         HIP_CHECK(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(ev_s, st));
-        launch_poly_h3(st, npad, nb, w);
+        if (b.use_basis) {
+            const int nbpad = ((nb + 127) / 128) * 128;
+            launch_basis_coef(st, h->P, b.k, b.basis_all, dZ, int0, nb, nbpad, w.coef);
+            ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis_all.cntpad * nb);
+            launch_basis_gemm(st, npad, nb, nbpad, b.basis_all, w.W[5], nullptr);
+        } else {
+            launch_poly_h3(st, npad, nb, w);
+        }
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 8); }
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
         { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
@@ -537,8 +579,8 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
         launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
         if (b.use_basis) {
             const int nbpad = ((nb + 127) / 128) * 128;
-            launch_basis_coef(st, h->P, b.k, b.basis[0], dZ, int0, nb, nbpad);
-            launch_basis_gemm(st, npad, nb, nbpad, b.basis[0], w.W[1]);
+            launch_basis_coef(st, h->P, b.k, b.basis[0], dZ, int0, nb, nbpad, nullptr);
+            launch_basis_gemm(st, npad, nb, nbpad, b.basis[0], w.W[1], nullptr);
         } else {
             launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]);
         }
@@ -589,7 +631,10 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
 }
 
 void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st) {
-    HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));  // fill!(∂, 0), evaluator.jl:497
+    // fill!(∂, 0), evaluator.jl:497 -- the -E_k block of a lone bilinear integrator is skipped: the chain
+    // overwrites all of it
+    if (h->bil.size() == 1 && h->P.n_int > 0) launch_jac_zero(st, h->P, h->bil[0].k, dvals);
+    else HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
     h->last_terms = 0;
     for (auto& b : h->bil) {
         Bounds bd{0, 0};

@@ -80,6 +80,7 @@ struct SweepTypes {
 struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices npad x npad each
     double* W[6];    // A, A2, A3, A4, Ha, Hb
     double* norms;   // [C][4]
+    double* colsum;  // [3][C][npad] column abs-sums of A^2..A^4 (basis path)
     double* coef;    // [C][COEF_STRIDE]
     int32_t* s;      // [C] squarings per interval
     int32_t* smax;   // [0] max, [1] sum of s over the chunk (read back by the host before the squarings)
@@ -183,12 +184,17 @@ void launch_add(hipStream_t st, double* dst, const double* src, int64_t n);  // 
 struct BasisSet {
     int32_t r, cnt, cntpad;     // degree, number of multisets, padded to 16
     const double* S;            // device [cntpad][npad^2]
-    const int32_t* idx;         // device [cnt][r] generator indices of each multiset
+    const int32_t* idx;         // device [cnt][r] generator indices of each multiset (-1 = unused slot)
     double* coef;               // device [capacity][cntpad] per-interval coefficients
 };
 void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const BasisSet& bs, const double* dZ,
-                       int64_t int0, int nb, int nbpad);
-void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out);
+                       int64_t int0, int nb, int nbpad, const double* taylor);
+void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals);
+// colsum (nullable): [nb][npad] accumulators of the column abs-sums of every output matrix (zeroed by
+// the caller); the exact 1-norms then cost no extra pass over the matrices.
+void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum);
+// norms[b*4 + which] = max_c colsum[b][c]
+void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which);
 // out2[0] = max_k min(b1_k, b2_k), out2[1] = max_k b1_k (bit patterns of non-negative doubles), where
 // b1_k >= ||A_k||_1 and b2_k >= ||A_k^2||_1^(1/2) follow from the generator norms g1[j] = ||G_j||_1,
 // n2[i][j] = ||G_i G_j||_1 and the triangle inequality.

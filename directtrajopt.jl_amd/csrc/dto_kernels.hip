@@ -63,7 +63,11 @@ void launch_add(hipStream_t st, double* dst, const double* src, int64_t n) {
 }
 
 // coef[b][alpha] = dt^r * prod_{i in alpha} ubar_i  (zero for padded intervals / padded multisets)
-__global__ void k_basis_coef(KProb P, KBil B, BasisSet bs, const double* __restrict__ Z, int64_t int0, int nb) {
+// H3 mode (taylor != nullptr): the set holds every multiset of degree 0..4 (idx padded with -1) and the
+// coefficient of a degree-r multiset is c_{12+r} sigma^{12+r} dt^r prod ubar, i.e. the output is the innermost
+// Paterson-Stockmeyer bracket H3 = c12 I + c13 A + c14 A^2 + c15 A^3 + c16 A^4.
+__global__ void k_basis_coef(KProb P, KBil B, BasisSet bs, const double* __restrict__ Z, int64_t int0, int nb,
+                             const double* __restrict__ taylor) {
     const int b = blockIdx.x;
     double* c = bs.coef + (int64_t)b * bs.cntpad;
     if (b >= nb) {
@@ -72,27 +76,31 @@ __global__ void k_basis_coef(KProb P, KBil B, BasisSet bs, const double* __restr
     }
     const double* zk = Z + (int0 + b) * P.z;
     const double dt = zk[P.dt_idx];
-    double dtr = dt;
-    for (int i = 1; i < bs.r; ++i) dtr *= dt;
     for (int a = threadIdx.x; a < bs.cntpad; a += blockDim.x) {
         double v = 0.0;
         if (a < bs.cnt) {
-            v = dtr;
+            v = 1.0;
+            int deg = 0;
             for (int i = 0; i < bs.r; ++i) {
                 const int g = bs.idx[a * bs.r + i];
+                if (g < 0) continue;
+                ++deg;
+                v *= dt;
                 if (g > 0) v *= zk[B.u_off + g - 1];
             }
+            if (taylor) v *= taylor[(int64_t)b * COEF_STRIDE + 12 + deg];
         }
         c[a] = v;
     }
 }
 void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const BasisSet& bs, const double* dZ,
-                       int64_t int0, int nb, int nbpad) {
-    hipLaunchKernelGGL(k_basis_coef, dim3(nbpad), dim3(128), 0, st, P, B, bs, dZ, int0, nb);
+                       int64_t int0, int nb, int nbpad, const double* taylor) {
+    hipLaunchKernelGGL(k_basis_coef, dim3(nbpad), dim3(128), 0, st, P, B, bs, dZ, int0, nb, taylor);
 }
 
 // out[:, b] = S * coef[:, b]  for the nb intervals of the chunk (FP64 MFMA, same GEMM core).
-__global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSet bs, double* __restrict__ out) {
+__global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSet bs, double* __restrict__ out,
+                                                       double* __restrict__ colsum) {
     using Cfg = GemmCfg<128, 128>;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
     const int64_t nn = (int64_t)npad * npad;
@@ -109,14 +117,39 @@ __global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSe
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = col0 + 16 * tj + 4 * r;
-            if (col >= nb) continue;
+            double asum = 0.0;
 #pragma unroll
-            for (int ti = 0; ti < Cfg::MT; ++ti) out[(int64_t)col * nn + row0 + 16 * ti] = acc.v[ti][tj][r];
+            for (int ti = 0; ti < Cfg::MT; ++ti) {
+                if (col < nb) out[(int64_t)col * nn + row0 + 16 * ti] = acc.v[ti][tj][r];
+                asum += fabs(acc.v[ti][tj][r]);
+            }
+            if (colsum) {
+                // the wave's 64 rows lie inside ONE column of the npad x npad matrix (npad multiple of 128):
+                // reduce over the 16 lanes sharing this interval, then one atomic per (interval, matrix column)
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
+                if ((threadIdx.x & 15) == 0 && col < nb)
+                    atomicAdd(&colsum[(int64_t)col * npad + (rt * 128 + (co.row_base & ~63)) / npad], asum);
+            }
         }
 }
-void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out) {
+__global__ void k_norm_from_colsum(int npad, int nb, const double* __restrict__ colsum, double* __restrict__ norms, int which) {
+    const int b = blockIdx.x;
+    double m = 0.0;
+    for (int c = threadIdx.x; c < npad; c += 64) m = fmax(m, colsum[(int64_t)b * npad + c]);
+    m = wave_max(m);
+    // NaN anywhere in the matrix must reach the scaling decision (fmax drops it)
+    double bad = 0.0;
+    for (int c = threadIdx.x; c < npad; c += 64) { const double v = colsum[(int64_t)b * npad + c]; if (!(v == v)) bad = 1.0; }
+    bad = wave_max(bad);
+    if (threadIdx.x == 0) norms[b * 4 + which] = bad > 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : m;
+}
+void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which) {
+    hipLaunchKernelGGL(k_norm_from_colsum, dim3(nb), dim3(64), 0, st, npad, nb, colsum, norms, which);
+}
+void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum) {
     const int64_t nn = (int64_t)npad * npad;
-    hipLaunchKernelGGL(k_basis_gemm, dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(256), 0, st, npad, nb, bs, out);
+    hipLaunchKernelGGL(k_basis_gemm, dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(256), 0, st, npad, nb, bs, out, colsum);
 }
 
 // One wavefront per column c of the owned knots: walk the column's entries in the structure's order
@@ -162,6 +195,28 @@ void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const
     if (ncols <= 0) return;
     if (transpose) hipLaunchKernelGGL(k_jac_spmv<1>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
     else hipLaunchKernelGGL(k_jac_spmv<0>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
+}
+
+// Zero-fill of the Jacobian slab (fill!(∂, 0), evaluator.jl:497) that skips the -E_k block of one bilinear
+// integrator: the propagator chain overwrites every entry of that block anyway (1 GB of 2.2 GB at 256x2000).
+__global__ void __launch_bounds__(256) k_jac_zero(KProb P, KBil B, double* __restrict__ vals) {
+    const int64_t kn = P.kn_lo + blockIdx.x;
+    const int has_prev = kn >= 1, has_own = kn < P.K;
+    const int cnt = has_prev + has_own;
+    const bool skipE = has_own && (int64_t)blockIdx.x < P.n_int;
+    const int64_t e_lo = (int64_t)B.pre * cnt + (has_prev ? B.n : 0);  // offset of the E rows inside an x column
+    for (int j = blockIdx.y; j < P.z; j += gridDim.y) {
+        const int64_t c = kn * P.z + j;
+        const int64_t e0 = P.colptr[c] - P.jac_lo, len = P.colptr[c + 1] - P.colptr[c];
+        const bool xcol = skipE && j >= B.x_off && j < B.x_off + B.n;
+        for (int64_t e = threadIdx.x; e < len; e += 256)
+            if (!(xcol && e >= e_lo && e < e_lo + B.n)) vals[e0 + e] = 0.0;
+    }
+}
+void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals) {
+    if (P.n_knots <= 0) return;
+    int gy = P.z < 32 ? P.z : 32;
+    hipLaunchKernelGGL(k_jac_zero, dim3((unsigned)P.n_knots, gy), dim3(256), 0, st, P, B, vals);
 }
 
 __global__ void k_norm_bounds(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1,
@@ -371,10 +426,16 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
             case 6: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2); return;
             case 7: launch_bgemm_shape<GemmShape<128, 128, 4, 2, 16>, EPI>(st, a, 2); return;
             case 8: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 8>, EPI>(st, a, 3); return;
-            default: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2); return;  // 8 waves: +6 % in the engine
+            default:
+                // measured in the engine (256x2000): the fused-polynomial epilogue hides better behind 8 waves,
+                // the plain / squaring products run faster with 4 waves of 64x64
+                if (EPI == EPI_HORNER) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+                else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
+                return;
         }
     } else if (a.npad % 128 == 0) {
-        launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+        if (EPI == EPI_HORNER) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+        else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
     } else {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
     }
