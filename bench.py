@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--callback", default="jacobian", choices=["jacobian", "hessian", "constraint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,11 +78,16 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -121,12 +128,17 @@ def main():
     elapsed = time.perf_counter() - t0
     ev.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ms_gemm, n_gemm, fl_gemm = ev.profile_get("bgemm")
     ms_sweep, n_sweep, fl_sweep = ev.profile_get("expmv")
+    variants = {}
+    for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("basis", "basis")):
+        ms_v, n_v, fl_v = ev.profile_get(nm)
+        if n_v:
+            variants[key] = {"launches": n_v, "avg_launch_ms": ms_v / n_v, "tflops": fl_v / (ms_v * 1e-3) / 1e12}
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
 
@@ -159,6 +171,7 @@ def main():
                 "launches": n_gemm, "avg_launch_ms": ms_gemm / max(n_gemm, 1),
                 "flops_per_launch": fl_gemm / max(n_gemm, 1),
                 "share_of_step": ms_gemm / (ms_per_step * args.steps) if ms_per_step > 0 else None,
+                "template_instances": variants,
             },
             "secondary_kernel": {"kernel": "k_sweep (generator sweep: exp(A)x and its u-tangents)",
                                  "ms_per_step": ms_sweep / args.steps, "launches": n_sweep,

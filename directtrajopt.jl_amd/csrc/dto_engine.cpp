@@ -187,7 +187,7 @@ struct ProfScope {
         h->prof.push_back(r);
     }
 };
-enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2 };
+enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BGEMM_SQUARE = 4 };
 
 // ------------------------------------------------------------------------------------------
 // structure
@@ -541,9 +541,9 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         } else {
             launch_poly_h3(st, npad, nb, w);
         }
-        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 8); }
-        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
-        { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
+        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 8); }
+        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
+        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
         HIP_CHECK(hipEventSynchronize(ev_s));
         HIP_CHECK(hipEventDestroy(ev_s));
         const int s_max = hs[0];
@@ -556,7 +556,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         h->last_smax = std::max(h->last_smax, s_max);
         int src = 4;
         for (int it = 0; it < s_max; ++it) {
-            ProfScope ps(h, st, CAT_BGEMM, sq_flops);
+            ProfScope ps(h, st, CAT_BGEMM_SQUARE, sq_flops);
             launch_bgemm_square(st, npad, nb, w, src, src == 4 ? 5 : 4, it, h->P, b.k, int0, vals);
             src = src == 4 ? 5 : 4;
         }
@@ -1238,13 +1238,19 @@ int dto_profile_reset(dto_handle* h) {
 int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops) {
     return guarded(h, [&] {
         int cat = -1;
-        if (!strcmp(name, "bgemm")) cat = CAT_BGEMM;
+        bool any_gemm = false;
+        if (!strcmp(name, "bgemm")) any_gemm = true;
+        else if (!strcmp(name, "bgemm_horner")) cat = CAT_BGEMM_HORNER;
+        else if (!strcmp(name, "bgemm_square")) cat = CAT_BGEMM_SQUARE;
+        else if (!strcmp(name, "bgemm_plain")) cat = CAT_BGEMM;
+        else if (!strcmp(name, "basis")) cat = CAT_OTHER;
         else if (!strcmp(name, "expmv")) cat = CAT_SWEEP;
         else if (strcmp(name, "all")) throw HipError{"dto_profile_get: unknown name"};
         double tot = 0, fl = 0;
         int64_t n = 0;
         for (auto& r : h->prof) {
-            if (cat >= 0 && r.cat != cat) continue;
+            if (any_gemm && r.cat != CAT_BGEMM && r.cat != CAT_BGEMM_HORNER && r.cat != CAT_BGEMM_SQUARE) continue;
+            if (!any_gemm && cat >= 0 && r.cat != cat) continue;
             HIP_CHECK(hipEventSynchronize(r.b));
             float t = 0;
             HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));

@@ -13,9 +13,11 @@
  *     (src/solvers/evaluator.jl:230, 474-482); component offsets are 0-based inside a knot.
  *   - Return value 0 = OK, non-zero = error; text via dto_last_error().
  *   - One in-flight call per handle (solvers call back serially).
- *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (passed as void*); they enqueue
- *     work and return without synchronising.  The plain entry points take HOST pointers, copy in/out
- *     and block until the result is in the caller's buffer.
+ *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (passed as void*); inputs and outputs
+ *     stay in HBM and the call returns with the last kernels still in flight on `stream`.  They may wait
+ *     on a few 8-16 byte device-to-host readbacks in between (data-dependent launch counts: squarings,
+ *     Taylor terms), so they are not graph-capturable.  The plain entry points take HOST pointers, copy
+ *     in/out and block until the result is in the caller's buffer.
  *   - A handle may own a SHARD of the knot range [k_lo, k_hi] (1-based, inclusive).  All value
  *     outputs are then the shard-local contiguous slabs described by dto_shard_info; with
  *     k_lo = 1, k_hi = N the slabs are the whole vectors.
@@ -159,7 +161,8 @@ int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const do
 /* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */
 int dto_profile_enable(dto_handle* h, int32_t on);
 int dto_profile_reset(dto_handle* h);
-/* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain), "expmv" (tangent step), "all".
+/* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain: every template instance), its parts
+ * "bgemm_horner" / "bgemm_square" / "bgemm_plain", "basis" (generator-subspace GEMM), "expmv" (sweep step), "all".
  * Returns accumulated device milliseconds, launches and algorithmic FLOPs of those launches. */
 int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops);
 /* diagnostics of the last Jacobian call: max squarings used, Taylor terms used by the tangent sweep */
