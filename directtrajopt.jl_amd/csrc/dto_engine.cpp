@@ -66,6 +66,8 @@ struct BilHost {
     double* d_n2 = nullptr;
     ChainWork chain{};
     int chain_cap = 0;
+    bool small = false;       // n <= 16: fused one-wavefront-per-interval path (dto_small.hip)
+    double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
     BasisSet basis[3]{};      // degrees 2, 3, 4
     BasisSet basis_all{};     // every multiset of degree 0..4: one GEMM gives the bracket H3
@@ -619,6 +621,10 @@ void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st)
 
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
     for (auto& b : h->bil) {
+        if (b.small) {
+            launch_small(st, h->P, b.k, b.d_Gs, make_types(0, false), make_types(0, false), dZ, nullptr, dg, nullptr, nullptr, 1);
+            continue;
+        }
         if (h->P.n_int > 0) {
             SweepPlan plan = plan_from(h, b, dZ, st);
             SweepTypes ty = make_types(0, false);
@@ -633,10 +639,14 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
 void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st) {
     // fill!(∂, 0), evaluator.jl:497 -- the -E_k block of a lone bilinear integrator is skipped: the chain
     // overwrites all of it
-    if (h->bil.size() == 1 && h->P.n_int > 0) launch_jac_zero(st, h->P, h->bil[0].k, dvals);
+    if (h->bil.size() == 1 && h->P.n_int > 0 && !h->bil[0].small) launch_jac_zero(st, h->P, h->bil[0].k, dvals);
     else HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
     h->last_terms = 0;
     for (auto& b : h->bil) {
+        if (b.small) {
+            launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, false), make_types(0, false), dZ, nullptr, nullptr, dvals, nullptr, 2);
+            continue;
+        }
         Bounds bd{0, 0};
         if (h->P.n_int > 0) {
             bd = get_bounds(h, b, dZ, st);
@@ -672,6 +682,10 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
         if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) {
             BilHost& b = h->bil[h->integ_index[i]];
             if (h->P.n_int <= 0) continue;
+            if (b.small) {
+                launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, true), make_types(b.k.m, false), dZ, dmu, nullptr, nullptr, dH, 4);
+                continue;
+            }
             SweepPlan plan = plan_from(h, b, dZ, st);
             SweepTypes ty2 = make_types(b.k.m, true);
             run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st);
@@ -722,6 +736,7 @@ void upload_Z(dto_handle* h, const double* Z) {
 void check_sweeps(dto_handle* h) {
     // after a synchronised call: the Taylor recurrences must have terminated inside their step budget
     for (auto& b : h->bil) {
+        if (b.small) continue;
         for (SweepBuf* w : {&b.fw, &b.ad}) {
             if (!w->stats) continue;
             int32_t st[2];
@@ -813,6 +828,11 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 if (!sonly) {
                     b.k.G = own(h, dupload(G));
                     b.k.GT = own(h, dupload(GT));
+                    static const bool small_on = [] { const char* e = getenv("DTO_SMALL_N"); return !e || atoi(e) != 0; }();
+                    if (small_on && n <= 16) {
+                        b.small = true;
+                        b.d_Gs = own(h, dupload(std::vector<double>(s.G, s.G + (size_t)m1 * n * n)));
+                    }
                 }
                 h->integ_index.push_back((int)h->bil.size());
                 h->bil.push_back(std::move(b));
@@ -986,6 +1006,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         // per-bilinear workspaces + generator product norms (for the step-budget bounds)
         for (auto& b : h->bil) {
             const int m = b.k.m;
+            if (b.small) {
+                if (d->eval_hessian && 1 + m + m * (m + 1) / 2 > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for second-order sweep"};
+                continue;  // the fused kernel needs no workspace
+            }
             const int T_fw = d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m;
             if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for second-order sweep (max 4 with eval_hessian)"};
             alloc_sweep(h, b, b.fw, T_fw, false);

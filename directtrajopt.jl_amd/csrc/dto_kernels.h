@@ -165,6 +165,12 @@ void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const S
 
 void launch_fill(hipStream_t st, double* p, int64_t n, double v);
 
+// Small-state path (dto_small.hip): one wavefront per interval, everything in LDS.  mode bits: 1 constraint
+// values, 2 Jacobian block, 4 Hessian block.  Gs = compact (m+1) x n x n generators.
+void launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* Gs, const SweepTypes& ty_fw,
+                  const SweepTypes& ty_ad, const double* dZ, const double* dmu, double* cons, double* jac, double* hess,
+                  int mode);
+
 // y = J w / y = J' w from the value slab in CSC order (A3: evaluator.jl:406-456; the reference also
 // materialises the Jacobian values first, on the host).  One wavefront per column.
 struct KIntegTable {

@@ -142,3 +142,31 @@ def test_jacobian_vector_products():
         assert rel_err(y, ev_o.eval_constraint_jacobian_product(p.Z0, w)) <= 1e-10
         assert rel_err(yt, ev_o.eval_constraint_jacobian_transpose_product(p.Z0, v)) <= 1e-10
         ev.close()
+
+
+def test_generic_path_on_small_states_in_subprocess():
+    """n <= 16 normally takes the fused small-state kernel; DTO_SMALL_N=0 forces the batched-GEMM path
+    (padding to 64, generator sweeps) on the same problems so both stay parity-checked."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os\n"
+        "root = os.environ['DTO_ROOT']\n"
+        "for p in (root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')): sys.path.insert(0, p)\n"
+        "import numpy as np, dto_amd, dto_oracle as O\n"
+        "from helpers import to_engine, rel_err, run_all\n"
+        "for p in (O.make_standard_problem(N=7), O.make_scaled_problem(5, 9, 3, seed=5, with_constraint=True), O.make_readme_problem()):\n"
+        "    ev_o = O.OracleEvaluator(p); ev = dto_amd.Evaluator(to_engine(p))\n"
+        "    mu = np.random.default_rng(1).standard_normal(ev_o.n_constraints)\n"
+        "    out = run_all(ev, p, p.Z0, mu, sigma=0.5)\n"
+        "    assert rel_err(out['cons'], ev_o.eval_constraint(p.Z0)) <= 1e-10\n"
+        "    assert rel_err(out['jac'], ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10\n"
+        "    assert rel_err(out['hess'], ev_o.eval_hessian_lagrangian(p.Z0, 0.5, mu)) <= 1e-8\n"
+        "    assert ev.last_stats()[0] >= 1  # the propagator chain ran\n"
+        "    ev.close()\n"
+        "print('generic-ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTO_SMALL_N="0", DTO_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "generic-ok" in r.stdout, r.stdout + r.stderr
