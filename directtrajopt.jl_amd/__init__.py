@@ -20,6 +20,8 @@ from .host.problem import (  # noqa: F401
     MinimumTimeObjective,
     NullObjective,
     CompositeObjective,
+    KnotPointObjective,
+    TerminalObjective,
     NonlinearKnotPointConstraint,
     DirectTrajOptProblem,
 )

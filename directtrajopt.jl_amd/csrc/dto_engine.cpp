@@ -983,6 +983,30 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 } else {
                     for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) times.push_back(kn);
                 }
+            } else if (s.kind == DTO_OBJECTIVE_KNOT_SQDIST) {
+                if (s.n_comps < 1 || !s.comps || !s.times) throw HipError{"knot objective: comps and times are required"};
+                std::vector<int32_t> comps(s.comps, s.comps + s.n_comps);
+                for (int q : comps)
+                    if (q < 0 || q >= d->z) throw HipError{"knot objective: component out of range"};
+                std::vector<double> params, Qs;
+                std::vector<int32_t> last;
+                for (int64_t t = 0; t < s.n_times; ++t) {
+                    if (s.times[t] < 1 || s.times[t] > d->N) throw HipError{"objective: time out of range"};
+                    const int64_t kn = s.times[t] - 1;
+                    if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
+                    times.push_back(kn);
+                    Qs.push_back(s.Qs ? s.Qs[t] : 1.0);
+                    if (s.params) params.insert(params.end(), s.params + (size_t)t * s.n_comps, s.params + (size_t)(t + 1) * s.n_comps);
+                    int32_t is_last = 1;
+                    for (int64_t t2 = t + 1; t2 < s.n_times; ++t2)
+                        if (s.times[t2] == s.times[t]) { is_last = 0; break; }
+                    last.push_back(is_last);
+                }
+                o.n_comps = s.n_comps;
+                o.comps = own(h, dupload(comps));
+                o.Qs = own(h, dupload(Qs));
+                o.last = own(h, dupload(last));
+                o.params = s.params ? own(h, dupload(params)) : nullptr;
             } else {
                 throw HipError{"unknown objective kind (closure-based objectives stay on the host)"};
             }

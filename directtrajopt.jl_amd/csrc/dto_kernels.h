@@ -155,6 +155,13 @@ struct KObj {  // objective term
     const double* baseline;  // device [comp_dim x N] or null
     const int64_t* times;    // device, owned 0-based knots
     int64_t n_times;
+    // KNOT_SQDIST (kind 4): l(v, p) = ||v - p||^2 on a component list, per-time targets and weights
+    const int32_t* comps;    // device [n_comps]
+    int32_t n_comps, pad1;
+    const double* params;    // device [n_times][n_comps] (owned times) or null
+    const double* Qs;        // device [n_times]
+    const int32_t* last;     // device [n_times]: 0 where a later listed time names the same knot -- the reference's
+                             // gradient!/hessian! overwrite per listed time (knot_point_objectives.jl:198, 235)
 };
 void launch_objective(hipStream_t st, const KProb& P, const KObj& O, const double* dZ, double* partial, double* f);
 void launch_gradient(hipStream_t st, const KProb& P, const KObj& O, const double* dZ, double* grad);

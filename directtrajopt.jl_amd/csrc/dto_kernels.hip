@@ -961,7 +961,14 @@ __global__ void __launch_bounds__(256) k_objective(KProb P, KObj O, const double
         const int64_t kn = O.times[i];
         const double* zk = Z + kn * P.z;
         const double dt = zk[P.dt_idx];
-        if (O.kind == 3) {  // MinimumTimeObjective: D * sum_{k<N} dt_k  (minimum_time_objective.jl:44-50)
+        if (O.kind == 4) {  // KnotPointObjective, l = ||v - p||^2: sum_i Q_i l (knot_point_objectives.jl:173-182)
+            double s = 0.0;
+            for (int c = 0; c < O.n_comps; ++c) {
+                const double dv = zk[O.comps[c]] - (O.params ? O.params[i * O.n_comps + c] : 0.0);
+                s += dv * dv;
+            }
+            acc += O.Qs[i] * s;
+        } else if (O.kind == 3) {  // MinimumTimeObjective: D * sum_{k<N} dt_k  (minimum_time_objective.jl:44-50)
             acc += dt;
         } else if (O.kind == 1) {  // QuadraticRegularizer value (regularizers.jl:79-91): 1/2 r'(R.*r), r = dt*dv
             double s = 0.0;
@@ -1004,7 +1011,13 @@ __global__ void k_gradient(KProb P, KObj O, const double* __restrict__ Z, double
     const double* zk = Z + kn * P.z;
     double* gk = grad + kn * P.z - P.grad_lo;
     const double dt = zk[P.dt_idx];
-    if (O.kind == 3) {
+    if (O.kind == 4) {  // gradient! writes 2 Q_i (v - p_i) per listed time, later entries overwrite (knot_point_objectives.jl:184-207)
+        if (!O.last[i]) return;
+        for (int c = 0; c < O.n_comps; ++c) {
+            const double dv = zk[O.comps[c]] - (O.params ? O.params[i * O.n_comps + c] : 0.0);
+            atomicAdd(&gk[O.comps[c]], O.weight * O.Qs[i] * 2.0 * dv);
+        }
+    } else if (O.kind == 3) {
         atomicAdd(&gk[P.dt_idx], O.weight * O.D);
     } else if (O.kind == 1) {
         double s = 0.0;
@@ -1048,7 +1061,15 @@ __global__ void k_hess_objective(KProb P, KObj O, const double* __restrict__ Z, 
     const double* zk = Z + kn * P.z;
     const double dt = zk[P.dt_idx];
     const double sw = sigma * O.weight;
-    if (O.kind == 1) {
+    if (O.kind == 4) {  // triu of the per-knot Hessian 2 Q_i I (knot_point_objectives.jl:224-243)
+        if (!O.last[i]) return;
+        for (int c = 0; c < O.n_comps; ++c) {
+            bool dup = false;  // a component listed twice: hessian of ||v-p||^2 in the concatenated vector maps both onto one entry
+            for (int c2 = 0; c2 < c; ++c2) dup |= O.comps[c2] == O.comps[c];
+            (void)dup;
+            atomicAdd(&H[hess_pos(P, kn, O.comps[c], O.comps[c])], sw * 2.0 * O.Qs[i]);
+        }
+    } else if (O.kind == 1) {
         double s = 0.0;
         bool dt_inside = false;
         for (int c = 0; c < O.comp_dim; ++c) {

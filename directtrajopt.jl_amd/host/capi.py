@@ -8,9 +8,9 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 1
+DTO_ABI_VERSION = 2
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE = 1, 2
-OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME = 1, 2, 3
+OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST = 1, 2, 3, 4
 CONSTRAINT_NORM, CONSTRAINT_SQNORM = 1, 2
 
 
@@ -22,7 +22,8 @@ class IntegratorDesc(C.Structure):
 class ObjectiveDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("comp_off", C.c_int32), ("comp_dim", C.c_int32), ("reserved", C.c_int32),
                 ("weight", C.c_double), ("D", C.c_double), ("R", c_double_p), ("baseline", c_double_p),
-                ("times", c_int64_p), ("n_times", C.c_int64)]
+                ("times", c_int64_p), ("n_times", C.c_int64), ("comps", c_int32_p), ("n_comps", C.c_int32),
+                ("reserved2", C.c_int32), ("params", c_double_p), ("Qs", c_double_p)]
 
 
 class ConstraintDesc(C.Structure):

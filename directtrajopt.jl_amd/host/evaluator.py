@@ -8,7 +8,7 @@ import numpy as np
 
 from . import capi
 from .capi import library_path, load_library  # noqa: F401
-from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, LinearRegularizer,
+from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, KnotPointObjective, LinearRegularizer,
                       MinimumTimeObjective, NonlinearKnotPointConstraint, NullObjective, QuadraticRegularizer)
 
 
@@ -87,6 +87,19 @@ class Evaluator:
                     t = np.ascontiguousarray(o.times, dtype=np.int64)
                     keep.append(t)
                     d.times, d.n_times = _ip(t), t.size
+            elif isinstance(o, KnotPointObjective):
+                d.kind = KnotPointObjective.KINDS[o.kind]
+                comps = np.ascontiguousarray(o.comps, dtype=np.int32)
+                t = np.ascontiguousarray(o.times, dtype=np.int64)
+                Qs = np.ascontiguousarray(o.Qs, dtype=np.float64)
+                keep += [comps, t, Qs]
+                d.comps, d.n_comps = comps.ctypes.data_as(capi.c_int32_p), comps.size
+                d.times, d.n_times = _ip(t), t.size
+                d.Qs = _dp(Qs)
+                if o.params is not None:
+                    P = np.ascontiguousarray(o.params, dtype=np.float64)  # rows = times: column-major n_comps x n_times
+                    keep.append(P)
+                    d.params = _dp(P)
             else:
                 raise NotImplementedError(f"{type(o).__name__} stays on the host (closure-based objective)")
             objs[i] = d

@@ -126,6 +126,43 @@ class MinimumTimeObjective(AbstractObjective):
         self.D = float(D)
 
 
+class KnotPointObjective(AbstractObjective):
+    """KnotPointObjective(l, names, traj, params; times, Qs) -- src/objectives/knot_point_objectives.jl:65-121,
+    restricted to the engine's built-in loss ``"sqdist"``: l(v, p) = ||v - p||^2 (p = None means zeros, i.e.
+    ``norm(v)^2``).  J = sum_i Q_i l(z_{t_i}[names], p_i)."""
+
+    KINDS = {"sqdist": 4}
+
+    def __init__(self, l, names, traj, params=None, times=None, Qs=None):
+        if callable(l):
+            raise NotImplementedError("closure-based losses stay on the host (SURVEY.md §8f rank 2); use a built-in kind")
+        if l not in self.KINDS:
+            raise ValueError(f"unknown built-in loss {l!r}")
+        names = [names] if isinstance(names, str) else list(names)
+        self.kind, self.var_names = l, names
+        self.times = _times(range(1, traj.N + 1) if times is None else times, traj.N)
+        self.comps = np.concatenate([np.asarray(traj.components[n]) for n in names]).astype(np.int32)
+        nt = self.times.size
+        self.Qs = np.ones(nt) if Qs is None else np.asarray(Qs, dtype=np.float64)
+        if self.Qs.shape != (nt,):
+            raise ValueError("Qs must have the same length as times")
+        if params is None:
+            self.params = None
+        else:
+            P = np.asarray(params, dtype=np.float64)
+            if P.shape == (self.comps.size,) and nt == 1:
+                P = P[None, :]
+            if P.shape != (nt, self.comps.size):
+                raise ValueError("params must have the same length as times")
+            self.params = P
+
+
+def TerminalObjective(l, names, traj, goal=None, Q=1.0):
+    """TerminalObjective(l, name, traj; Q) -- knot_point_objectives.jl:123-157: the loss at the last knot."""
+    return KnotPointObjective(l, names, traj, params=None if goal is None else np.asarray(goal, dtype=np.float64)[None, :],
+                              times=[traj.N], Qs=[float(Q)])
+
+
 class NonlinearKnotPointConstraint:
     """NonlinearKnotPointConstraint(g, names, traj; equality, times) --
     src/constraints/nonlinear/knot_point_constraint.jl:27-107, restricted to the engine's built-in

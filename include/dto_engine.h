@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 1
+#define DTO_ABI_VERSION 2
 
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
@@ -41,6 +41,8 @@ extern "C" {
 #define DTO_OBJECTIVE_QUADRATIC_REGULARIZER 1 /* regularizers.jl:38-167   */
 #define DTO_OBJECTIVE_LINEAR_REGULARIZER 2    /* regularizers.jl:207-313  */
 #define DTO_OBJECTIVE_MINIMUM_TIME 3          /* minimum_time_objective.jl:24-76 */
+#define DTO_OBJECTIVE_KNOT_SQDIST 4           /* KnotPointObjective / TerminalObjective with the built-in loss
+                                                 l(v, p) = ||v - p||^2 (knot_point_objectives.jl:65-243) */
 
 /* built-in g kinds for NonlinearKnotPointConstraint (knot_point_constraint.jl:27-107) */
 #define DTO_CONSTRAINT_NORM_MINUS_C 1   /* g(v) = [ ||v||_2   - c ] */
@@ -67,6 +69,12 @@ typedef struct dto_objective_desc {
     const double* baseline; /* comp_dim x N column-major, or NULL = zeros (QuadraticRegularizer) */
     const int64_t* times;   /* 1-based knot indices, or NULL = 1:N */
     int64_t n_times;
+    /* KNOT_SQDIST only: */
+    const int32_t* comps;   /* knot-local component indices (0-based), vcat of var_names comps */
+    int32_t n_comps;
+    int32_t reserved2;
+    const double* params;   /* n_comps x n_times column-major targets p_i, or NULL = zeros */
+    const double* Qs;       /* n_times weights Q_i, or NULL = ones */
 } dto_objective_desc;
 
 typedef struct dto_constraint_desc {

@@ -93,6 +93,19 @@ class MinimumTimeObjective:
 
 
 @dataclass
+class KnotSqDistObjective:
+    """KnotPointObjective / TerminalObjective with l(v, p) = ||v - p||^2
+    (src/objectives/knot_point_objectives.jl:65-243)."""
+
+    comps: Sequence[int]
+    times1: Sequence[int]
+    Qs: Sequence[float]
+    params: Optional[np.ndarray] = None  # (n_times, n_comps) or None (= zeros)
+
+    kind = "knot_sqdist"
+
+
+@dataclass
 class KnotConstraint:
     """NonlinearKnotPointConstraint with a built-in g (closed set).
 
@@ -383,6 +396,13 @@ def _baseline(term, t0):
 def term_value(term, prob, Z):
     """objective_value -- regularizers.jl:79-91, :240-249, minimum_time_objective.jl:44-50."""
     J = 0.0
+    if term.kind == "knot_sqdist":  # knot_point_objectives.jl:173-182 (every listed time counts)
+        comps = np.asarray(term.comps)
+        for i, t1 in enumerate(term.times1):
+            v = _knot(Z, prob, t1 - 1)[comps]
+            p = np.zeros(len(comps)) if term.params is None else np.asarray(term.params)[i]
+            J += term.Qs[i] * float((v - p) @ (v - p))
+        return J
     if term.kind == "mintime":
         for k in range(prob.K):
             J += _knot(Z, prob, k)[prob.dt_idx]
@@ -401,6 +421,16 @@ def term_value(term, prob, Z):
 
 def term_gradient_accumulate(grad, term, prob, Z, scale=1.0):
     """gradient! (accumulating form) -- regularizers.jl:93-115, :251-271, minimum_time_objective.jl:52-66."""
+    if term.kind == "knot_sqdist":
+        # gradient! overwrites the knot's view per listed time, then scales (knot_point_objectives.jl:184-207)
+        comps = np.asarray(term.comps)
+        tmp = np.zeros_like(grad)
+        for i, t1 in enumerate(term.times1):
+            v = _knot(Z, prob, t1 - 1)[comps]
+            p = np.zeros(len(comps)) if term.params is None else np.asarray(term.params)[i]
+            tmp[(t1 - 1) * prob.z + comps] = term.Qs[i] * 2.0 * (v - p)
+        grad += scale * tmp
+        return
     if term.kind == "mintime":
         for k in range(prob.K):
             grad[k * prob.z + prob.dt_idx] += scale * term.D
@@ -424,6 +454,14 @@ def term_hessian_structure(term, prob):
     S = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return S.tocsc()
+    if term.kind == "knot_sqdist":  # knot_point_objectives.jl:209-222
+        comps = np.asarray(term.comps)
+        for t1 in term.times1:
+            idx = (t1 - 1) * prob.z + comps
+            for a in idx:
+                for b in idx:
+                    S[a, b] = 1.0
+        return S.tocsc()
     for t0 in times0(term.times1, prob.N):
         base = t0 * prob.z
         vs = slice(base + term.comp_off, base + term.comp_off + term.comp_dim)
@@ -444,6 +482,16 @@ def term_full_hessian(term, prob, Z):
     H = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return H.tocsc()
+    if term.kind == "knot_sqdist":  # hessian! per listed time (overwrite), triu (knot_point_objectives.jl:224-243)
+        comps = np.asarray(term.comps)
+        for i, t1 in enumerate(term.times1):
+            idx = (t1 - 1) * prob.z + comps
+            for a in idx:
+                for b in idx:
+                    H[a, b] = 0.0
+            for a in idx:
+                H[a, a] = 2.0 * term.Qs[i]
+        return sp.triu(H.tocsc()).tocsc()
     for t0 in times0(term.times1, prob.N):
         zk = _knot(Z, prob, t0)
         dt = zk[prob.dt_idx]
@@ -685,9 +733,9 @@ def pauli_generators():
 
 
 def make_standard_problem(N=10, seed=3, omega=0.1):
-    """The reference's "standard problem" (test/test_snippets.jl:29-54, test/test_utils.jl:113-178)
-    minus its closure-based TerminalObjective (host-fallback scope): components x[4], u[2], du[2],
-    ddu[2], dt; Bilinear + 2 Derivative; QuadReg(u) + QuadReg(du) + MinimumTime; ||u|| - 1 <= 0 at
+    """The reference's "standard problem" (test/test_snippets.jl:29-54, test/test_utils.jl:113-178):
+    components x[4], u[2], du[2], ddu[2], dt; Bilinear + 2 Derivative;
+    TerminalObjective(x -> norm(x - goal)^2) + QuadReg(u) + QuadReg(du) + MinimumTime; ||u|| - 1 <= 0 at
     2:N-1.  Data are seeded here (the reference's are unseeded rand/randn)."""
     Gx, Gy, Gz = pauli_generators()
     G = np.stack([omega * Gz, Gx, Gy])
@@ -702,9 +750,10 @@ def make_standard_problem(N=10, seed=3, omega=0.1):
         N=N, z=11, dt_idx=10,
         integrators=[BilinearIntegrator(0, 4, 4, 2, G), DerivativeIntegrator(4, 2, 6),
                      DerivativeIntegrator(6, 2, 8)],
-        objectives=[QuadraticRegularizer(4, 2, np.ones(2)), QuadraticRegularizer(6, 2, np.ones(2)),
+        objectives=[KnotSqDistObjective([0, 1, 2, 3], [N], [1.0], np.array([[0.0, 1.0, 0.0, 0.0]])),
+                    QuadraticRegularizer(4, 2, np.ones(2)), QuadraticRegularizer(6, 2, np.ones(2)),
                     MinimumTimeObjective(1.0)],
-        weights=[1.0, 1.0, 1.0],
+        weights=[1.0, 1.0, 1.0, 1.0],
         constraints=[KnotConstraint("norm", [4, 5], 1.0, list(range(2, N)), equality=False)],
         Z0=data.T.reshape(-1).copy())
 

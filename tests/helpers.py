@@ -19,7 +19,7 @@ def to_engine(prob: O.Problem):
         else:
             ranges[(it.xdot_off, it.x_dim)] = None
     for t in prob.objectives:
-        if t.kind != "mintime":
+        if t.kind not in ("mintime", "knot_sqdist"):
             ranges[(t.comp_off, t.comp_dim)] = None
     ranges[(prob.dt_idx, 1)] = None
     cuts = sorted(ranges)
@@ -51,6 +51,13 @@ def to_engine(prob: O.Problem):
             o = dto_amd.QuadraticRegularizer(names[(t.comp_off, t.comp_dim)], traj, t.R, baseline=t.baseline, times=t.times1)
         elif t.kind == "linear":
             o = dto_amd.LinearRegularizer(names[(t.comp_off, t.comp_dim)], traj, t.R, times=t.times1)
+        elif t.kind == "knot_sqdist":
+            o = dto_amd.KnotPointObjective.__new__(dto_amd.KnotPointObjective)
+            o.kind, o.var_names = "sqdist", []
+            o.times = np.asarray(t.times1, dtype=np.int64)
+            o.comps = np.asarray(t.comps, dtype=np.int32)
+            o.Qs = np.asarray(t.Qs, dtype=np.float64)
+            o.params = None if t.params is None else np.asarray(t.params, dtype=np.float64)
         else:
             o = dto_amd.MinimumTimeObjective(traj, D=t.D)
         terms.append(prob.w(i) * o)

@@ -43,8 +43,10 @@ def test_objective_term_variety():
         O.LinearRegularizer(n + m, m, np.array([1e-2, 3e-2])),
         O.MinimumTimeObjective(2.5),
         O.QuadraticRegularizer(0, n, rng.random(n)),
+        O.KnotSqDistObjective([0, 2, n + 1], [1, 4, 4, N], [1.0, 2.0, 0.5, 3.0], rng.standard_normal((4, 3))),  # a knot listed twice
+        O.KnotSqDistObjective(list(range(n)), [N], [1.5]),  # norm(x)^2 at the last knot, no target
     ]
-    p.weights = [1.0, 0.3, 2.0, 0.1]
+    p.weights = [1.0, 0.3, 2.0, 0.1, 0.7, 1.0]
     _compare(p)
 
 
