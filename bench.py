@@ -116,11 +116,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    ev.profile_enable(True)  # warm-up runs with the timing events on too; they are recycled by profile_reset
     for _ in range(args.warmup):
         step()
     fence()
     ev.profile_reset()
-    ev.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -134,6 +134,7 @@ struct dto_handle {
 
     bool profiling = false;
     std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;  // recycled timing events (creating them inside the timed region costs host time)
     int last_smax = 0, last_terms = 0;
     std::vector<void*> owned;  // device allocations to free
 
@@ -147,6 +148,7 @@ dto_handle::~dto_handle() {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
+    for (auto& e : ev_pool) (void)hipEventDestroy(e);
     for (void* p : owned) (void)hipFree(p);
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (stream) (void)hipStreamDestroy(stream);
@@ -179,8 +181,12 @@ struct ProfScope {
         if (!on) return;
         r.cat = cat;
         r.flops = flops;
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
+        auto take = [&](hipEvent_t& e) {
+            if (h->ev_pool.empty()) (void)hipEventCreate(&e);
+            else { e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+        };
+        take(r.a);
+        take(r.b);
         (void)hipEventRecord(r.a, st);
     }
     ~ProfScope() {
@@ -1276,10 +1282,22 @@ int dto_eval_jacobian_transpose_product(dto_handle* h, const double* Z, const do
 }
 
 // ---- measurement
-int dto_profile_enable(dto_handle* h, int32_t on) { if (!h) return 1; h->profiling = on != 0; return 0; }
+int dto_profile_enable(dto_handle* h, int32_t on) {
+    if (!h) return 1;
+    if (on && !h->structure_only && h->ev_pool.size() < 1024) {
+        (void)hipSetDevice(h->device);
+        while (h->ev_pool.size() < 1024) {  // enough for ~8 calls without touching the allocator in the timed region
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            h->ev_pool.push_back(e);
+        }
+    }
+    h->profiling = on != 0;
+    return 0;
+}
 int dto_profile_reset(dto_handle* h) {
     if (!h) return 1;
-    for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& r : h->prof) { h->ev_pool.push_back(r.a); h->ev_pool.push_back(r.b); }
     h->prof.clear();
     return 0;
 }

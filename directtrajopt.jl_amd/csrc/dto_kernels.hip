@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSe
             double asum = 0.0;
 #pragma unroll
             for (int ti = 0; ti < Cfg::MT; ++ti) {
-                if (col < nb) out[(int64_t)col * nn + row0 + 16 * ti] = acc.v[ti][tj][r];
+                if (col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
                 asum += fabs(acc.v[ti][tj][r]);
             }
             if (colsum) {
@@ -361,7 +361,7 @@ k_bgemm(BGemmArgs a) {
 #pragma unroll
                     for (int ti = 0; ti < Cfg::MT; ++ti) {
                         const int row = row0 + 16 * ti;
-                        if (row < n) a.vals[base + row] = -acc.v[ti][tj][r];
+                        if (row < n) __builtin_nontemporal_store(-acc.v[ti][tj][r], &a.vals[base + row]);  // never re-read by the engine
                     }
                 }
             continue;
@@ -386,10 +386,11 @@ k_bgemm(BGemmArgs a) {
                     const int64_t off = (int64_t)col * a.npad + row;
                     double v2 = acc.v[ti][tj][r];
                     if (EPI == EPI_HORNER) {
-                        v2 += c1 * M1[off] + c2 * M2[off] + c3 * M3[off];
+                        v2 += c1 * __builtin_nontemporal_load(&M1[off]) + c2 * __builtin_nontemporal_load(&M2[off]) +
+                              c3 * __builtin_nontemporal_load(&M3[off]);  // streamed once per stage
                         if (row == col) v2 += c0;
                     }
-                    Cb[off] = v2;
+                    __builtin_nontemporal_store(v2, &Cb[off]);  // 1 GB per launch: gone from L2 before its reader starts
                 }
             }
     }
