@@ -71,6 +71,11 @@ struct BilHost {
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
     BasisSet basis[3]{};      // degrees 2, 3, 4
     BasisSet basis_all{};     // every multiset of degree 0..4: one GEMM gives the bracket H3
+    // Hessian pairing path: stored Taylor terms of both sweeps, E_j * forward terms, Beta-weighted adjoint sums
+    bool pairing = false;
+    double* EP = nullptr;
+    double* Upair = nullptr;
+    double* d_Btab = nullptr;
 };
 
 struct ConHost {
@@ -352,8 +357,10 @@ SweepPlan plan_sweep(double beta) {
     return p;
 }
 
-void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
-               int src_kind, int transposed, const SweepPlan& plan, hipStream_t st) {
+// Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
+// (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
+int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
+              int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false) {
     const double flops_step = [&] {
         double segs = 0;
         for (int t = 0; t < ty.T; ++t) {
@@ -362,19 +369,31 @@ void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, con
         }
         return 2.0 * b.k.npad * (double)b.k.npad * w.Kpad * segs;
     }();
-    launch_sweep_init(st, h->P, b.k, w, ty, dZ, dmu, src_kind, plan.q);
+    const size_t tstride = (size_t)ty.T * w.Kpad * w.npad;
+    SweepBuf ws = w;
+    if (store) ws.Z[0] = w.Zt;
+    launch_sweep_init(st, h->P, b.k, ws, ty, dZ, dmu, src_kind, plan.q);
+    int launched = 0;
     for (int round = 0; round < plan.q; ++round) {
         if (round > 0) launch_sweep_restart(st, w, ty.T);
         int buf = 0;
+        launched = 0;
         bool pending = false;
         int slot = 0;
         for (int t = 0; t < plan.d_ub; ++t) {
             {
                 ProfScope ps(h, st, CAT_SWEEP, flops_step);
-                launch_sweep_step(st, b.k, w, ty, transposed, t, buf);
+                if (store) {
+                    ws.Z[0] = w.Zt + (size_t)t * tstride;
+                    ws.Z[1] = w.Zt + (size_t)(t + 1) * tstride;
+                    launch_sweep_step(st, b.k, ws, ty, transposed, t, 0);
+                } else {
+                    launch_sweep_step(st, b.k, w, ty, transposed, t, buf);
+                }
             }
             launch_sweep_check(st, w, ty.T, t, 1.1e-16);
             buf ^= 1;
+            launched = t + 1;
             // Every 4 steps the number of still-active column blocks (4 bytes) is copied back; the copy of the
             // PREVIOUS checkpoint is read before enqueueing more, so the host never waits on the GPU's current
             // work (the decision lags by 4 steps, which then cost ~5 us each as inactive blocks exit at once).
@@ -391,6 +410,7 @@ void run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, con
             }
         }
     }
+    return launched;
 }
 
 // multisets of size r over {0..m} as sorted tuples, lexicographic
@@ -702,16 +722,29 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 continue;
             }
             SweepPlan plan = plan_from(h, b, dZ, st);
-            SweepTypes ty2 = make_types(b.k.m, true);
-            run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st);
+            const bool pair = b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
+            SweepTypes ty2 = make_types(b.k.m, !pair);
+            const int steps_f = run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st, pair);
             launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
             // W_j = G_j' mu from the adjoint sweep's term-0 buffer, then the adjoint sweep itself
             launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
             launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
             SweepTypes ty1 = make_types(b.k.m, false);
-            run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st);
+            const int steps_a = run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair);
             launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
-            launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH);
+            launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
+            if (pair) {
+                // (u_i,u_j) block from the stored Taylor terms of the two first-order sweeps (no second-order
+                // columns): E_j * forward terms, Beta-weighted sums of the adjoint terms, then dot products
+                const int nf = steps_f + 1, na = steps_a + 1, T1 = 1 + b.k.m;
+                const int64_t cols = (int64_t)nf * T1 * b.fw.Kpad;
+                {
+                    ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * b.k.m);
+                    launch_apply_generators_cols(st, b.k, b.fw, 0, b.fw.Zt, b.EP, 1, b.k.m, cols);
+                }
+                launch_pair_combine(st, b.ad, T1, nf, na, b.fw.nterms, b.d_Btab, b.Upair);
+                launch_hess_pair(st, h->P, b.k, b.fw, nf, b.Upair, b.EP, dH);
+            }
         } else {
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
         }
@@ -1053,7 +1086,30 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             const int T_fw = d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m;
             if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for second-order sweep (max 4 with eval_hessian)"};
             alloc_sweep(h, b, b.fw, T_fw, false);
-            if (d->eval_hessian) alloc_sweep(h, b, b.ad, 1 + m, true);
+            if (d->eval_hessian) {
+                alloc_sweep(h, b, b.ad, 1 + m, true);
+                // pairing path: term stores for both sweeps + E_j*terms + Beta-weighted sums (skipped when it
+                // would not fit a 24 GB budget: the second-order sweep is then used)
+                const int dcap = 64, T1 = 1 + m;
+                const double bytes = (double)dcap * T1 * b.fw.Kpad * b.k.npad * 8.0;
+                static const bool pair_on = [] { const char* e = getenv("DTO_HESS_PAIRING"); return !e || atoi(e) != 0; }();
+                if (pair_on && m >= 1 && bytes * (3 + m) < 24e9) {
+                    const size_t store = (size_t)dcap * T1 * b.fw.Kpad * b.k.npad;
+                    for (SweepBuf* w : {&b.fw, &b.ad}) {
+                        w->Zt = own(h, dalloc<double>(store));
+                        w->dcap = dcap;
+                        w->nterms = own(h, dalloc<int32_t>(w->Kpad / w->TN));
+                        HIP_CHECK(hipMemset(w->nterms, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
+                    }
+                    b.EP = own(h, dalloc<double>(store * m));
+                    b.Upair = own(h, dalloc<double>(store));
+                    std::vector<double> bt(64 * 64);
+                    for (int a = 0; a < 64; ++a)
+                        for (int c = 0; c < 64; ++c) bt[a * 64 + c] = std::exp(std::lgamma(a + 1.0) + std::lgamma(c + 1.0) - std::lgamma(a + c + 2.0));
+                    b.d_Btab = own(h, dupload(bt));
+                    b.pairing = true;
+                }
+            }
             const int npad = b.k.npad;
             alloc_chain(h, b, std::max(chunk_size(h, npad), (m + 1) * (m + 1)));
             // N2[i][j] = ||G_i G_j||_1 with the engine's own batched GEMM + norm kernels

@@ -111,6 +111,10 @@ struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear i
     unsigned long long* sumnorm;   // [T][Kpad]
     int32_t* active;   // [Kpad/TN]
     int32_t* stats;    // [0] active blocks after the last check, [1] terms used (max)
+    // term store (Hessian pairing path): every Taylor term of the sweep is kept, [dcap][T][Kpad][npad]
+    double* Zt;
+    int32_t dcap, pad2;
+    int32_t* nterms;   // [Kpad/TN] number of valid terms of a converged column block (0: use all launched)
 };
 
 // src_kind: 0 = state x_k of the integrator (forward sweep), 1 = multipliers mu_k (adjoint sweep)
@@ -123,6 +127,15 @@ void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double 
 // out[j] = G_j (or G_j') * V for every generator j (no summation): out [(m+1)][Kpad][npad]
 void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
                              double* out);
+// out[g] = G_{gen_first+g} * V over `cols` columns (cols multiple of the sweep tile): the pairing path's E_j * terms
+void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
+                                  double* out, int gen_first, int gen_count, int64_t cols);
+// U[a][type][k][:] = sum_b Btab[a][b] * terms[b][type][k][:]   (Beta-function weights of the pairing formula)
+void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int nf_used, int na_used, const int32_t* nterms_f,
+                         const double* Btab, double* U);
+// (u_i,u_j) block of the bilinear Hessian from the pairing formula (see k_hess_pair)
+void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* U,
+                      const double* EP, double* H);
 // GY = sum_j ubar_j G_j (or G_j') * V
 void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V, double* out);
 
@@ -168,7 +181,7 @@ void launch_gradient(hipStream_t st, const KProb& P, const KObj& O, const double
 void launch_hess_objective(hipStream_t st, const KProb& P, const KObj& O, const double* dZ, double sigma, double* H);
 void launch_hess_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dmu, double* H);
 void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad,
-                          const double* dmu, double* H);
+                          const double* dmu, double* H, int with_uu);
 
 void launch_fill(hipStream_t st, double* p, int64_t n, double v);
 

@@ -29,6 +29,8 @@ namespace dto {
 __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 __device__ __forceinline__ double bits_to_d(unsigned long long b) { return __longlong_as_double((long long)b); }
 
+__device__ __forceinline__ void hess_add(const KProb& P, double* H, int64_t kn, int a, int b, double v);
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -591,7 +593,10 @@ __global__ void __launch_bounds__(256) k_sweep_init(KProb P, KBil B, SweepBuf w,
             w.scaleU[(int64_t)j * w.Kpad + k] = ub;
             w.scaleA[(int64_t)j * w.Kpad + k] = dt * ub * inv_q;
         }
-        if (k % w.TN == 0) w.active[k / w.TN] = 1;
+        if (k % w.TN == 0) {
+            w.active[k / w.TN] = 1;
+            if (w.nterms) w.nterms[k / w.TN] = 0;
+        }
         if (k == 0) { w.stats[0] = w.Kpad / w.TN; w.stats[1] = 0; }
     }
 }
@@ -773,6 +778,105 @@ void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, i
     a.B = B; a.w = w; a.G = transposed ? B.GT : B.G; a.mode = 1; a.V = V; a.out = out;
     launch_sweep_kernel(st, a, B.m + 1);
 }
+void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
+                                  double* out, int gen_first, int gen_count, int64_t cols) {
+    SweepArgs a{};
+    a.B = B; a.w = w;
+    a.w.Kpad = (int32_t)cols;  // the kernel only uses Kpad as the column count / generator stride in this mode
+    a.G = (transposed ? B.GT : B.G) + (int64_t)gen_first * B.npad * B.npad;
+    a.mode = 1; a.V = V; a.out = out;
+    launch_sweep_kernel(st, a, gen_count);
+}
+
+// U[a][type][k][r] = sum_{b < na} Btab[a][b] * terms[b][type][k][r]  for a < nf (valid term counts per column block)
+__global__ void __launch_bounds__(256) k_pair_combine(SweepBuf ad, int T, int nf_used, int na_used,
+                                                     const int32_t* __restrict__ nterms_f, const double* __restrict__ Btab,
+                                                     double* __restrict__ U) {
+    const int64_t typesz = (int64_t)ad.Kpad * ad.npad;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (k, r)
+    if (e >= typesz) return;
+    const int type = blockIdx.y;
+    const int ct = (int)((e / ad.npad) / ad.TN);
+    int nf = nterms_f[ct], na = ad.nterms[ct];
+    if (nf <= 0 || nf > nf_used) nf = nf_used;
+    if (na <= 0 || na > na_used) na = na_used;
+    const int64_t tstride = (int64_t)T * typesz;
+    const double* src = ad.Zt + type * typesz + e;
+    double* dst = U + type * typesz + e;
+    for (int a0 = 0; a0 < nf; a0 += 8) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < na; ++b) {
+            const double v = src[b * tstride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += Btab[(a0 + q) * 64 + b] * v;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (a0 + q < nf) dst[(a0 + q) * tstride] = acc[q];
+    }
+}
+void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int nf_used, int na_used, const int32_t* nterms_f,
+                         const double* Btab, double* U) {
+    const int64_t typesz = (int64_t)ad.Kpad * ad.npad;
+    hipLaunchKernelGGL(k_pair_combine, dim3((unsigned)((typesz + 255) / 256), T), dim3(256), 0, st, ad, T, nf_used, na_used,
+                       nterms_f, Btab, U);
+}
+
+// (u_i, u_j) block of mu_k' f by the pairing formula
+//   d2/du_i du_j [mu' exp(A) x] = sum_{a,b} B(a,b) ( dt~^i_b ' E_j p_a + pt_b ' E_j d^i_a ),  B(a,b) = a! b! / (a+b+1)!
+// (the Taylor terms of exp(tau A)x and exp((1-tau)A')mu integrate against each other over tau in [0,1]);
+// p_a, d^i_a: forward sweep terms, pt_b, dt~^i_b: adjoint sweep terms, U = the b-sums, EP[j] = G_j * forward terms.
+__global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw, int nf_used, const double* __restrict__ U,
+                                                   const double* __restrict__ EP, double* __restrict__ H) {
+    __shared__ double red[4][MAX_DRIVES * MAX_DRIVES];
+    const int64_t kl = blockIdx.x;
+    const int64_t kn = P.kn_lo + kl;
+    const int n = B.n, m = B.m, npad = fw.npad, T = 1 + m;
+    const int64_t typesz = (int64_t)fw.Kpad * npad;
+    const int64_t tstride = (int64_t)T * typesz;          // one Taylor term of all types
+    const int64_t gstride = (int64_t)nf_used * tstride;   // one generator in EP (cols = nf_used*T*Kpad)
+    int nf = fw.nterms[kl / fw.TN];
+    if (nf <= 0 || nf > nf_used) nf = nf_used;
+    double acc[MAX_DRIVES][MAX_DRIVES];
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) acc[i][j] = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const int64_t off = kl * npad + r;
+        for (int a = 0; a < nf; ++a) {
+            const double* Ua = U + a * tstride + off;
+            const double* Ea = EP + a * tstride + off;
+            const double V = Ua[0];
+            for (int i = 0; i < m; ++i) {
+                const double Ui = Ua[(1 + i) * typesz];
+                for (int j = 0; j < m; ++j)
+                    acc[i][j] += Ui * Ea[j * gstride] + V * Ea[j * gstride + (1 + i) * typesz];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            const double v = wave_sum(acc[i][j]);
+            if (lane == 0) red[wave][i * MAX_DRIVES + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < m * m) {
+        const int i = threadIdx.x / m, j = threadIdx.x % m;
+        if (i <= j) {
+            auto tot = [&](int a2, int b2) { return red[0][a2 * MAX_DRIVES + b2] + red[1][a2 * MAX_DRIVES + b2] +
+                                                    red[2][a2 * MAX_DRIVES + b2] + red[3][a2 * MAX_DRIVES + b2]; };
+            const double dt = fw.scaleE[kl];  // dt/q with q = 1 on this path
+            const double v = 0.5 * (tot(i, j) + tot(j, i));  // equal in exact arithmetic (mixed partials)
+            hess_add(P, H, kn, B.u_off + i, B.u_off + j, -dt * v);
+        }
+    }
+}
+void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* U,
+                      const double* EP, double* H) {
+    if (P.n_int <= 0) return;
+    hipLaunchKernelGGL(k_hess_pair, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, nf_used, U, EP, H);
+}
+
 void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V, double* out) {
     SweepArgs a{};
     a.B = B; a.w = w; a.G = transposed ? B.GT : B.G; a.mode = 2; a.V = V; a.out = out;
@@ -803,6 +907,7 @@ __global__ void __launch_bounds__(64) k_sweep_check(SweepBuf w, int T, int t, do
     if (lane == 0) {
         if (conv) {
             w.active[ct] = 0;
+            if (w.nterms) w.nterms[ct] = t + 2;  // terms 0..t+1 are in the store
             atomicSub(&w.stats[0], 1);
         } else {
             atomicMax(&w.stats[1], t + 2);
@@ -1150,7 +1255,7 @@ void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const doubl
 //   (u_i,u_j)  = -mu' h_ij           (u_j, dt)  = -(W_j' y + Gm' c_j)
 //   (dt, dt)   = -Gm' (G(u) y)       (G(u) y = fw.GY)
 __global__ void __launch_bounds__(256) k_hess_bilinear(KProb P, KBil B, SweepBuf fw, SweepBuf ad,
-                                                        const double* __restrict__ mu, double* __restrict__ H) {
+                                                        const double* __restrict__ mu, double* __restrict__ H, int with_uu) {
     __shared__ double sm[4];
     const int64_t kl = blockIdx.x;
     const int64_t kn = P.kn_lo + kl;
@@ -1170,7 +1275,7 @@ __global__ void __launch_bounds__(256) k_hess_bilinear(KProb P, KBil B, SweepBuf
         return s;
     };
     int hidx = 1 + m;
-    for (int i = 0; i < m; ++i)
+    for (int i = 0; i < (with_uu ? m : 0); ++i)
         for (int j = i; j < m; ++j, ++hidx) {
             double s = 0.0;
             for (int r = threadIdx.x; r < n; r += blockDim.x) s += muk[r] * fw.S[hidx * ts + col + r];
@@ -1194,9 +1299,9 @@ __global__ void __launch_bounds__(256) k_hess_bilinear(KProb P, KBil B, SweepBuf
     }
 }
 void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad,
-                          const double* dmu, double* H) {
+                          const double* dmu, double* H, int with_uu) {
     if (P.n_int <= 0) return;
-    hipLaunchKernelGGL(k_hess_bilinear, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, ad, dmu, H);
+    hipLaunchKernelGGL(k_hess_bilinear, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, ad, dmu, H, with_uu);
 }
 
 }  // namespace dto

@@ -172,3 +172,12 @@ def test_generic_path_on_small_states_in_subprocess():
     env = dict(os.environ, DTO_SMALL_N="0", DTO_ROOT=root)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "generic-ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_large_norm_on_the_general_path_uses_substeps_and_many_squarings():
+    """n > 16 with big time steps: the sweeps need q > 1 rounds (which also takes the Hessian off the
+    pairing path, onto second-order columns) and the chain several squarings."""
+    p = O.make_scaled_problem(4, 24, 3, seed=24)
+    Z = p.Z0.copy()
+    Z[p.dt_idx::p.z] = [2.0, 0.7, 1.3, 0.1]
+    _compare(p, Z=Z, tol=1e-9, tol_h=1e-7)
