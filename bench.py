@@ -142,6 +142,13 @@ def main():
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
 
+    traffic, traffic_src = None, None
+    try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_k_bgemm.json")))
+        if (n, Nk, args.callback) == (256, 2000, "jacobian"):
+            traffic, traffic_src = tj["avg_per_launch_bytes"], tj["source"]
+    except Exception:
+        pass
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         achieved = fl_gemm / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
@@ -167,7 +174,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": n_gemm, "avg_launch_ms": ms_gemm / max(n_gemm, 1),
                 "flops_per_launch": fl_gemm / max(n_gemm, 1),
                 "share_of_step": ms_gemm / (ms_per_step * args.steps) if ms_per_step > 0 else None,
