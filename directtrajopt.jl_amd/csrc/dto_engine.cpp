@@ -1084,7 +1084,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 continue;  // the fused kernel needs no workspace
             }
             const int T_fw = d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m;
-            if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for second-order sweep (max 4 with eval_hessian)"};
+            if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for the second-order sweep"};
             alloc_sweep(h, b, b.fw, T_fw, false);
             if (d->eval_hessian) {
                 alloc_sweep(h, b, b.ad, 1 + m, true);

@@ -9,7 +9,7 @@ namespace dto {
 constexpr int TAYLOR_M = 16;                 // degree of the matrix Taylor polynomial
 constexpr double THETA_16 = 0.78028743;      // backward-error radius of T_16 in double (Al-Mohy & Higham 2011, Table 3.1 method)
 constexpr int COEF_STRIDE = 20;              // doubles per interval in the coefficient table
-constexpr int MAX_TYPES = 16;                // column types of a generator sweep (p, d^i, h^{ij})
+constexpr int MAX_TYPES = 36;                // column types of a generator sweep (p, d^i, h^{ij})
 constexpr int MAX_DRIVES = 7;
 
 // Problem-level constants every kernel may need.

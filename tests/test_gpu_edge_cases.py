@@ -181,3 +181,9 @@ def test_large_norm_on_the_general_path_uses_substeps_and_many_squarings():
     Z = p.Z0.copy()
     Z[p.dt_idx::p.z] = [2.0, 0.7, 1.3, 0.1]
     _compare(p, Z=Z, tol=1e-9, tol_h=1e-7)
+
+
+@pytest.mark.parametrize("n,m", [(6, 5), (20, 6), (9, 7)])
+def test_many_drives(n, m):
+    """More than 4 drives: 1+m+m(m+1)/2 second-order column types (up to 36 at m = 7)."""
+    _compare(O.make_scaled_problem(4, n, m, seed=n * m, with_constraint=True))
