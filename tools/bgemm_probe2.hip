@@ -166,7 +166,8 @@ int main(int argc, char** argv) {
     run<128, 128, 2, 4, 16, 0, 2>("128x128 8w(2x4) KB16 2wg/cu", A, B, C, npad, nb, 2);
     run<128, 128, 4, 2, 16, 0, 2>("128x128 8w(4x2) KB16 2wg/cu", A, B, C, npad, nb, 2);
     run<256, 128, 4, 2, 16, 0, 2>("256x128 8w(4x2) KB16 1wg/cu", A, B, C, npad, nb, 1);
-    run<256, 256, 4, 4, 8, 0, 1>("256x256 16w(4x4) KB8 1wg/cu", A, B, C, npad, nb, 1);
-    run<128, 128, 2, 2, 16, 0, 2>("128x128 4w KB16 3wg/cu?", A, B, C, npad, nb, 3);
+    run<128, 128, 2, 2, 8, 0, 3>("128x128 4w KB8 3wg/cu (<=168 VGPR)", A, B, C, npad, nb, 3);
+    run<128, 128, 2, 2, 4, 0, 3>("128x128 4w KB4 3wg/cu (<=168 VGPR)", A, B, C, npad, nb, 3);
+    run<128, 128, 2, 2, 8, 0, 2>("128x128 4w KB8 2wg/cu", A, B, C, npad, nb, 2);
     return 0;
 }
