@@ -360,7 +360,8 @@ SweepPlan plan_sweep(double beta) {
 // Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
-              int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false) {
+              int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false,
+              bool skip_init = false) {
     const double flops_step = [&] {
         double segs = 0;
         for (int t = 0; t < ty.T; ++t) {
@@ -372,7 +373,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
     const size_t tstride = (size_t)ty.T * w.Kpad * w.npad;
     SweepBuf ws = w;
     if (store) ws.Z[0] = w.Zt;
-    launch_sweep_init(st, h->P, b.k, ws, ty, dZ, dmu, src_kind, plan.q);
+    if (!skip_init) launch_sweep_init(st, h->P, b.k, ws, ty, dZ, dmu, src_kind, plan.q);
     int launched = 0;
     for (int round = 0; round < plan.q; ++round) {
         if (round > 0) launch_sweep_restart(st, w, ty.T);
@@ -1083,7 +1084,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 if (d->eval_hessian && 1 + m + m * (m + 1) / 2 > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for second-order sweep"};
                 continue;  // the fused kernel needs no workspace
             }
-            const int T_fw = d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m;
+            const int T_fw = std::max(2 + m, d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m);  // +1: exp(A)w_x column of J w
             if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for the second-order sweep"};
             alloc_sweep(h, b, b.fw, T_fw, false);
             if (d->eval_hessian) {
@@ -1311,8 +1312,52 @@ int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double*
     });
 }
 
+// Matrix-free products for handles whose bilinear integrators all take the general path: exp(A)w_x rides the
+// forward sweep as an extra column type (J w), exp(A')w_k is an adjoint sweep (J' w); no value slab is formed.
+static void jac_product_matrix_free(dto_handle* h, const double* dZ, const double* dw, double* dy, int transpose, hipStream_t st) {
+    const int64_t n_out = transpose ? h->n_vars : h->n_cons;
+    HIP_CHECK(hipMemsetAsync(dy, 0, sizeof(double) * (size_t)n_out, st));  // fill!(y, 0), evaluator.jl:416,442
+    for (auto& b : h->bil) {
+        if (h->P.n_int <= 0) continue;
+        SweepPlan plan = plan_from(h, b, dZ, st);
+        SweepTypes ty = make_types(b.k.m, false);
+        if (!transpose) {
+            const int tw = ty.T;
+            ty.t[ty.T++] = TypeDesc{0, {0, 0}, {0, 0}, {0, 0}};  // exp(A) w_x: a second "p" column
+            SweepBuf ws = b.fw;
+            launch_sweep_init(st, h->P, b.k, ws, ty, dZ, nullptr, 0, plan.q);
+            launch_sweep_set_type(st, h->P, b.k, ws, ty.T, tw, dw);
+            run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st, false, /*skip_init=*/true);
+            launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+            launch_jv_bilinear(st, h->P, b.k, b.fw, tw, dw, dy);
+        } else {
+            run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
+            launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+            run_sweep(h, b, b.ad, make_types(0, false), dZ, dw, 1, 1, plan, st);
+            launch_jtv_bilinear(st, h->P, b.k, b.fw, b.ad, dw, dy);
+        }
+    }
+    for (auto& d : h->der) launch_jv_derivative(st, h->P, d, dZ, dw, dy, transpose);
+    for (auto& c : h->con) launch_jv_knot(st, h->P, c.k, dZ, dw, dy, transpose);
+}
+
 static void jac_product(dto_handle* h, const double* Z, const double* w, double* y, int transpose) {
     if (h->k_lo != 1 || h->k_hi != h->N) throw HipError{"Jacobian-vector products need an unsharded handle"};
+    bool mfree = h->eval_hessian != 0 || transpose == 0;  // the adjoint sweep buffers exist only with eval_hessian
+    for (auto& b : h->bil) mfree = mfree && !b.small && (transpose == 0 || b.ad.S != nullptr) && b.k.m + 2 <= MAX_TYPES;
+    static const bool mfree_on = [] { const char* e = getenv("DTO_JV_MATRIX_FREE"); return !e || atoi(e) != 0; }();
+    if (mfree && mfree_on) {
+        const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;
+        if (!h->d_w) h->d_w = own(h, dalloc<double>((size_t)std::max(h->n_vars, h->n_cons)));
+        upload_Z(h, Z);
+        HIP_CHECK(hipMemcpyAsync(h->d_w, w, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, h->stream));
+        double* o = staging(h, (size_t)n_out);
+        jac_product_matrix_free(h, h->d_Z, h->d_w, o, transpose, h->stream);
+        HIP_CHECK(hipMemcpyAsync(y, o, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        check_sweeps(h);
+        return;
+    }
     if (h->integ_kind.size() > 8) throw HipError{"Jacobian-vector products support at most 8 integrators"};
     const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;
     if (!h->d_jac_scratch) {

@@ -121,6 +121,16 @@ struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear i
 void launch_sweep_init(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
                        const double* dZ, const double* dmu, int src_kind, int q);
 void launch_sweep_restart(hipStream_t st, const SweepBuf& w, int T);
+// term 0 (and sum) of column type `type` := v[kn*z + x_off + :]  (a second start vector, Z layout): exp(A) v rides
+// along the same sweep as an extra column type
+void launch_sweep_set_type(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, int T, int type, const double* v);
+// matrix-free Jacobian-vector products (evaluator.jl:406-456 without materialising J)
+//   Jw:  y[rows of the integrator] = -exp(A)w_x - sum_j c_j w_uj - G(u)y w_dt + w_x(k+1)   (type_ew = column type of exp(A) w_x)
+//   Jtw: y[knot entries] += -exp(A')w_k (+ w_{k-1}), -c_j'w_k, -(G(u)y)'w_k                 (ad.S[0] = exp(A') w_k)
+void launch_jv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int type_ew, const double* w, double* y);
+void launch_jtv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad, const double* w, double* y);
+void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const double* dZ, const double* w, double* y, int transpose);
+
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
                        int t, int in_buf);
 void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);
@@ -158,6 +168,7 @@ struct KCon {  // NonlinearKnotPointConstraint with a built-in g
                              // ForwardDiff.hessian! into the block view overwrites (knot_point_constraint.jl:285-291)
 };
 void launch_cons_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* g);
+void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* w, double* y, int transpose);
 void launch_jac_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* vals);
 void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* dmu, double* H);
 

@@ -42,6 +42,13 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
 __global__ void k_fill(double* p, int64_t n, double v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -605,6 +612,32 @@ void launch_sweep_init(hipStream_t st, const KProb& P, const KBil& B, const Swee
     hipLaunchKernelGGL(k_sweep_init, dim3(w.Kpad), dim3(256), 0, st, P, B, w, ty.T, dZ, dmu, src_kind, 1.0 / q);
 }
 
+__global__ void __launch_bounds__(256) k_sweep_set_type(KProb P, KBil B, SweepBuf w, int T, int type, const double* __restrict__ v) {
+    const int k = blockIdx.x;
+    const bool live = k < P.n_int;
+    const int64_t kn = P.kn_lo + k;
+    const int64_t base = ((int64_t)type * w.Kpad + k) * w.npad;
+    double mx = 0.0;
+    for (int r = threadIdx.x; r < w.npad; r += blockDim.x) {
+        const double x = (live && r < B.n) ? v[kn * P.z + B.x_off + r] : 0.0;
+        w.Z[0][base + r] = x;
+        w.S[base + r] = x;
+        mx = fmax(mx, fabs(x));
+    }
+    __shared__ double sm[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        w.termnorm[(0 * T + type) * (int64_t)w.Kpad + k] = dbits(mx);
+        w.sumnorm[(int64_t)type * w.Kpad + k] = dbits(mx);
+    }
+}
+void launch_sweep_set_type(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, int T, int type, const double* v) {
+    hipLaunchKernelGGL(k_sweep_set_type, dim3(w.Kpad), dim3(256), 0, st, P, B, w, T, type, v);
+}
+
 // Next sub-interval of a q-fold split exp(A) = exp(A/q)^q: the sums become term 0 of the new series.
 __global__ void __launch_bounds__(256) k_sweep_restart(SweepBuf w, int T) {
     const int k = blockIdx.x, t = blockIdx.y;
@@ -1049,15 +1082,110 @@ void launch_jac_knot(hipStream_t st, const KProb& P, const KCon& C, const double
 }
 
 // ============================================================================================
+// matrix-free Jacobian-vector products (A3 without the value slab)
+// ============================================================================================
+__global__ void k_jv_bilinear(KProb P, KBil B, SweepBuf fw, int type_ew, const double* __restrict__ w, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_int * B.n) return;
+    const int64_t kl = i / B.n;
+    const int r = (int)(i % B.n);
+    const int64_t kn = P.kn_lo + kl;
+    const int64_t ts = (int64_t)fw.Kpad * fw.npad, col = kl * fw.npad + r;
+    const double* wk = w + kn * P.z;
+    double v = -fw.S[type_ew * ts + col] - fw.GY[col] * wk[P.dt_idx] + w[(kn + 1) * P.z + B.x_off + r];
+    for (int j = 0; j < B.m; ++j) v -= fw.S[(1 + j) * ts + col] * wk[B.u_off + j];
+    y[B.row_off + kn * B.n + r] = v;
+}
+void launch_jv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int type_ew, const double* w, double* y) {
+    const int64_t n = P.n_int * B.n;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_jv_bilinear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, B, fw, type_ew, w, y);
+}
+
+__global__ void __launch_bounds__(256) k_jtv_bilinear(KProb P, KBil B, SweepBuf fw, SweepBuf ad, const double* __restrict__ w,
+                                                       double* __restrict__ y) {
+    __shared__ double sm[4];
+    const int64_t kl = blockIdx.x;
+    const int64_t kn = P.kn_lo + kl;
+    const int n = B.n;
+    const int64_t ts = (int64_t)fw.Kpad * fw.npad, col = kl * fw.npad;
+    double* yk = y + kn * P.z;
+    const bool own = kn < P.K && kl < P.n_int;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        double v = 0.0;
+        if (own) v -= ad.S[col + r];                                   // -exp(A_k)' w_k
+        if (kn >= 1) v += w[B.row_off + (kn - 1) * n + r];             // +I' w_{k-1}
+        atomicAdd(&yk[B.x_off + r], v);
+    }
+    if (!own) return;
+    const double* wk = w + B.row_off + kn * n;
+    for (int j = 0; j <= B.m; ++j) {   // j < m: u_j entries, j == m: the timestep entry
+        double s = 0.0;
+        const double* c = j < B.m ? fw.S + (1 + j) * ts + col : fw.GY + col;
+        for (int r = threadIdx.x; r < n; r += 256) s += c[r] * wk[r];
+        s = block_sum_256(s, sm);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&yk[j < B.m ? B.u_off + j : P.dt_idx], -s);
+    }
+}
+void launch_jtv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad, const double* w, double* y) {
+    if (P.n_knots <= 0) return;
+    hipLaunchKernelGGL(k_jtv_bilinear, dim3((unsigned)P.n_knots), dim3(256), 0, st, P, B, fw, ad, w, y);
+}
+
+// DerivativeIntegrator rows: -w_x - dt w_xdot - xdot w_dt + w_x(k+1)   and the transpose
+__global__ void k_jv_derivative(KProb P, KDer D, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y,
+                                int transpose) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_int * D.d) return;
+    const int64_t kl = i / D.d;
+    const int r = (int)(i % D.d);
+    const int64_t kn = P.kn_lo + kl;
+    const double* zk = Z + kn * P.z;
+    const int64_t row = D.row_off + kn * D.d + r;
+    if (!transpose) {
+        const double* wk = w + kn * P.z;
+        y[row] = -wk[D.x_off + r] - zk[P.dt_idx] * wk[D.xdot_off + r] - zk[D.xdot_off + r] * wk[P.dt_idx] + wk[P.z + D.x_off + r];
+    } else {
+        const double wr = w[row];
+        double* yk = y + kn * P.z;
+        atomicAdd(&yk[D.x_off + r], -wr);
+        atomicAdd(&yk[D.xdot_off + r], -zk[P.dt_idx] * wr);
+        atomicAdd(&yk[P.dt_idx], -zk[D.xdot_off + r] * wr);
+        atomicAdd(&yk[P.z + D.x_off + r], wr);
+    }
+}
+void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const double* dZ, const double* w, double* y, int transpose) {
+    const int64_t n = P.n_int * D.d;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_jv_derivative, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, D, dZ, w, y, transpose);
+}
+
+// knot constraints: only entries inside the pattern taken at Z0 take part (evaluator.jl:545-547)
+__global__ void k_jv_knot(KProb P, KCon C, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y, int transpose) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C.n_times * C.n_comps) return;
+    if (C.jpos[i] < 0) return;
+    const int64_t ti = i / C.n_comps;
+    const int c = (int)(i % C.n_comps);
+    const int64_t kn = C.times[ti];
+    const double* zk = Z + kn * P.z;
+    const double v = zk[C.comps[c]];
+    const double jac = C.kind == 1 ? v / sqrt(knot_norm2(P, C, zk)) : 2.0 * v;
+    const int64_t row = C.mu_off + C.tidx[ti], colg = kn * P.z + C.comps[c];
+    if (!transpose) atomicAdd(&y[row], jac * w[colg]);
+    else atomicAdd(&y[colg], jac * w[row]);
+}
+void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* w, double* y, int transpose) {
+    const int64_t n = C.n_times * C.n_comps;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_jv_knot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, C, dZ, w, y, transpose);
+}
+
+// ============================================================================================
 // objectives (O1-O4)
 // ============================================================================================
 
-__device__ __forceinline__ double block_sum_256(double v, double* sm) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sm[0] + sm[1] + sm[2] + sm[3];
-}
 
 // partial[b] = sum over this block's times of the term value
 __global__ void __launch_bounds__(256) k_objective(KProb P, KObj O, const double* __restrict__ Z, double* __restrict__ partial) {

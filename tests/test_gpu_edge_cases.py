@@ -187,3 +187,20 @@ def test_large_norm_on_the_general_path_uses_substeps_and_many_squarings():
 def test_many_drives(n, m):
     """More than 4 drives: 1+m+m(m+1)/2 second-order column types (up to 36 at m = 7)."""
     _compare(O.make_scaled_problem(4, n, m, seed=n * m, with_constraint=True))
+
+
+def test_matrix_free_products_on_the_general_path():
+    """n > 16: J w and J' w come from the sweeps (exp(A)w_x as an extra column type / an adjoint sweep from w),
+    no value slab; checked against the oracle's materialise-and-multiply."""
+    import dto_amd
+    for p in (O.make_scaled_problem(5, 20, 3, seed=77, with_constraint=True), O.make_scaled_problem(4, 70, 2, seed=78)):
+        ev_o = O.OracleEvaluator(p)
+        ev = dto_amd.Evaluator(to_engine(p))
+        rng = np.random.default_rng(6)
+        w = rng.standard_normal(p.n_vars)
+        v = rng.standard_normal(ev_o.n_constraints)
+        y = np.full(ev_o.n_constraints, np.nan); ev.eval_constraint_jacobian_product(y, p.Z0, w)
+        yt = np.full(p.n_vars, np.nan); ev.eval_constraint_jacobian_transpose_product(yt, p.Z0, v)
+        assert rel_err(y, ev_o.eval_constraint_jacobian_product(p.Z0, w)) <= 1e-10
+        assert rel_err(yt, ev_o.eval_constraint_jacobian_transpose_product(p.Z0, v)) <= 1e-10
+        ev.close()
