@@ -879,10 +879,11 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
             const double* Ua = U + a * tstride + off;
             const double* Ea = EP + a * tstride + off;
             const double V = Ua[0];
+            double Ep[MAX_DRIVES];  // G_j p_a: shared by every i
+            for (int j = 0; j < m; ++j) Ep[j] = Ea[j * gstride];
             for (int i = 0; i < m; ++i) {
                 const double Ui = Ua[(1 + i) * typesz];
-                for (int j = 0; j < m; ++j)
-                    acc[i][j] += Ui * Ea[j * gstride] + V * Ea[j * gstride + (1 + i) * typesz];
+                for (int j = 0; j < m; ++j) acc[i][j] += Ui * Ep[j] + V * Ea[j * gstride + (1 + i) * typesz];
             }
         }
     }
