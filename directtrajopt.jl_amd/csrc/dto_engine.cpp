@@ -1089,12 +1089,14 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             alloc_sweep(h, b, b.fw, T_fw, false);
             if (d->eval_hessian) {
                 alloc_sweep(h, b, b.ad, 1 + m, true);
-                // pairing path: term stores for both sweeps + E_j*terms + Beta-weighted sums (skipped when it
-                // would not fit a 24 GB budget: the second-order sweep is then used)
+                // pairing path: term stores for both sweeps + E_j*terms + Beta-weighted sums (skipped when they
+                // would take more than 40 % of the free HBM: the second-order sweep is then used)
                 const int dcap = 64, T1 = 1 + m;
                 const double bytes = (double)dcap * T1 * b.fw.Kpad * b.k.npad * 8.0;
                 static const bool pair_on = [] { const char* e = getenv("DTO_HESS_PAIRING"); return !e || atoi(e) != 0; }();
-                if (pair_on && m >= 1 && bytes * (3 + m) < 24e9) {
+                size_t free_b = 0, total_b = 0;
+                HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                if (pair_on && m >= 1 && bytes * (3 + m) < 0.4 * (double)free_b) {
                     const size_t store = (size_t)dcap * T1 * b.fw.Kpad * b.k.npad;
                     for (SweepBuf* w : {&b.fw, &b.ad}) {
                         w->Zt = own(h, dalloc<double>(store));

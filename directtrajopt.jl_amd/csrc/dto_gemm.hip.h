@@ -136,11 +136,17 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
             for (int ti = 0; ti < C::MT; ++ti) af[ti] = as[(kk + lq) * C::LDA_S + 16 * ti];
 #pragma unroll
             for (int tj = 0; tj < C::NT; ++tj) bf[tj] = bs[16 * tj * C::LDB_S + kk + lq];
+#ifdef DTO_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int ti = 0; ti < C::MT; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < C::NT; ++tj)
                     acc.v[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[tj], af[ti], acc.v[ti][tj], 0, 0, 0);
+#ifdef DTO_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         if (kb + 1 < nkb) store_panel(buf ^ 1);
         __syncthreads();
