@@ -152,6 +152,68 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
         __syncthreads();
     }
 }
+// DMA-staged form (operands unscaled): the K panels go global -> LDS directly with `global_load_lds_dwordx4`
+// (1 KB per wave-instruction, no staging registers, no ds_write).  The LDS images are unpadded because a DMA
+// piece must be wave-contiguous; conflicts are avoided by the SOURCE permutation instead:
+//   As[k][m'] , m' = (m + 16 (k & 1)) mod TM   -- the two k's of a 32-lane ds_read_b64 group land 128 B apart
+//   Bs[kp][c][2]                                -- the two k's of a k-pair are adjacent: a group reads 256 contiguous B
+// Requires TM = TN = 128, KB = 16 (A: 16 pieces/panel, B: 16 pieces/panel, spread over the workgroup's waves).
+#define DTO_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define DTO_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+template <class C>
+__device__ __forceinline__ void gemm_accumulate_dma(GemmAccS<C>& acc, const double* __restrict__ A, int lda,
+                                                    const double* __restrict__ B, int ldb, int Klen, double* smem) {
+    static_assert(C::TM == 128 && C::TN == 128 && C::KB == 16, "DMA staging is laid out for 128x128x16 panels");
+    constexpr int TM = 128, TN = 128, KB = 16, AS = KB * TM, BS = KB * TN;
+    constexpr int NW = C::THREADS / 64, PPW = 16 / NW;  // pieces per wave and operand
+    static_assert(2 * (AS + BS) <= C::SMEM_DOUBLES, "LDS budget");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WC, wn = wave % C::WC;
+    const int lr = lane & 15, lq = lane >> 4;
+    double* As = smem;
+    double* Bs = smem + 2 * AS;
+    auto dma_panel = [&](int kb, int buf) {
+        const int k0 = kb * KB;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int k = wave + NW * q;
+            const int m = (2 * lane - 16 * (k & 1)) & (TM - 1);
+            __builtin_amdgcn_global_load_lds(DTO_GLB_PTR(A + (size_t)(k0 + k) * lda + m), DTO_LDS_PTR(As + buf * AS + k * TM), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int piece = wave + NW * q;
+            const int g = piece * 64 + lane;
+            const int kp = g / TN, c = g % TN;
+            __builtin_amdgcn_global_load_lds(DTO_GLB_PTR(B + (size_t)c * ldb + k0 + 2 * kp), DTO_LDS_PTR(Bs + buf * BS + piece * 128), 16, 0, 0);
+        }
+    };
+    const int nkb = Klen / KB;
+    dma_panel(0, 0);
+    __syncthreads();  // its fence waits for the DMA (vmcnt(0)) before the barrier
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) dma_panel(kb + 1, buf ^ 1);
+        const double* as = As + buf * AS;
+        const double* bs = Bs + buf * BS;
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            const int k = kk + lq;
+            double af[C::MT], bf[C::NT];
+#pragma unroll
+            for (int ti = 0; ti < C::MT; ++ti) af[ti] = as[k * TM + ((wm * C::WTM + 16 * ti + lr + 16 * (k & 1)) & (TM - 1))];
+#pragma unroll
+            for (int tj = 0; tj < C::NT; ++tj) bf[tj] = bs[(k >> 1) * (TN * 2) + (wn * C::WTN + 16 * tj + lr) * 2 + (k & 1)];
+#pragma unroll
+            for (int ti = 0; ti < C::MT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < C::NT; ++tj)
+                    acc.v[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[tj], af[ti], acc.v[ti][tj], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const double* __restrict__ A, int lda,
                                                 const double* __restrict__ B, int ldb, int Klen,

@@ -327,10 +327,10 @@ struct BGemmArgs {
 // PERSISTENT: the grid is sized to the chip (2 workgroups per CU) and every workgroup walks the
 // (interval, tile) list with a stride of gridDim.x; this removes the workgroup re-dispatch gaps that a
 // one-tile-per-workgroup grid of ~8000 short workgroups shows (measured: 25 % of wall time).
-template <class Cfg, int EPI>
+template <class Cfg, int EPI, bool DMA = false>
 __global__ void __launch_bounds__(Cfg::THREADS, (Cfg::THREADS / 256) * (Cfg::SMEM_DOUBLES * 8 > 80 * 1024 ? 1 : 2))
 k_bgemm(BGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
+    __shared__ __attribute__((aligned(1024))) double smem[Cfg::SMEM_DOUBLES];
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     const int tiles_r = a.npad / TM;
     const int tpm = tiles_r * (a.npad / TN);
@@ -351,7 +351,8 @@ k_bgemm(BGemmArgs a) {
 
         GemmAccS<Cfg> acc;
         acc.zero();
-        gemm_accumulate_s<Cfg>(acc, Ab, a.npad, Bb, a.npad, a.npad, nullptr, smem);
+        if constexpr (DMA) gemm_accumulate_dma<Cfg>(acc, Ab, a.npad, Bb, a.npad, a.npad, smem);
+        else gemm_accumulate_s<Cfg>(acc, Ab, a.npad, Bb, a.npad, a.npad, nullptr, smem);
 
         const int row0 = tr * TM + co.row_base, col0 = tc * TN + co.col_base;
 
@@ -405,22 +406,39 @@ k_bgemm(BGemmArgs a) {
     }
 }
 
-static int bgemm_grid_cap() {
-    // persistent grid: workgroups per CU x 256 CUs (multiple of 8 so the XCD label of a workgroup is
-    // the same for every tile it walks); DTO_BGEMM_WGS_PER_CU=0 restores one workgroup per tile
-    static int v = [] { const char* e = getenv("DTO_BGEMM_WGS_PER_CU"); return e ? atoi(e) : 2; }();
-    return v * 256;
-}
 static int bgemm_shape_choice() {
     static int v = [] { const char* e = getenv("DTO_BGEMM_SHAPE"); return e ? atoi(e) : -1; }();
     return v;
 }
+static int bgemm_dma_choice() {  // -1: per-epilogue default, 0/1: forced
+    static int v = [] { const char* e = getenv("DTO_BGEMM_DMA"); return e ? atoi(e) : -1; }();
+    return v;
+}
+static int bgemm_wgs_choice() {  // -1: per-epilogue default, 0: one workgroup per tile, k: k persistent workgroups per CU
+    static int v = [] { const char* e = getenv("DTO_BGEMM_WGS_PER_CU"); return e ? atoi(e) : -1; }();
+    return v;
+}
+// Measured in the engine at 256x2000 (ms per launch, fused-polynomial / squaring):
+//   register staging, persistent 1.48 / 1.25    register staging, one WG per tile 1.37 / 1.27
+//   DMA staging,      persistent 1.56 / 1.20    DMA staging,      one WG per tile 1.47 / 1.23
+// so the polynomial products run one workgroup per tile with register staging, the plain products and the
+// squarings run persistent with DMA staging.
 template <class Cfg, int EPI>
 static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_cu) {
     int grid = batch_tile_count(a.nbatch, (a.npad / Cfg::TM) * (a.npad / Cfg::TN));
-    const int cap = bgemm_grid_cap() > 0 ? wgs_per_cu * 256 : 0;
-    if (cap > 0 && grid > cap) grid = cap;
-    hipLaunchKernelGGL((k_bgemm<Cfg, EPI>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+    int wgs = bgemm_wgs_choice();
+    if (wgs < 0) wgs = EPI == EPI_HORNER ? 0 : wgs_per_cu;
+    else if (wgs > 0) wgs = wgs_per_cu;
+    if (wgs > 0 && grid > wgs * 256) grid = wgs * 256;
+    if constexpr (Cfg::TM == 128 && Cfg::TN == 128 && Cfg::KB == 16) {
+        int dma = bgemm_dma_choice();
+        if (dma < 0) dma = EPI == EPI_HORNER ? 0 : 1;
+        if (dma) {
+            hipLaunchKernelGGL((k_bgemm<Cfg, EPI, true>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_bgemm<Cfg, EPI, false>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
 }
 template <int EPI>
 static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
