@@ -697,47 +697,13 @@ struct SweepArgs {
     double* out;
 };
 
-// One Taylor step of the sweep for every owned interval at once:
-//   term_{t+1}[type] = 1/(t+1) * ( sum_j G_j * (term_t[type] .* dt ubar_j/q)  +  sum_extra G_g * (term_t[src] .* dt/q * mult) )
-// i.e. a GEMM whose K dimension is the concatenation of the generator blocks, the per-interval
-// bilinear coefficients being applied to the B panel while it is staged into LDS.
+// Epilogue shared by the sweep kernels: store the new term, accumulate the sums and the column norms (Taylor
+// step), or just store the product (modes 1, 2).
 template <int TM, int TN>
-__global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(SweepArgs a) {
+__device__ __forceinline__ void sweep_epilogue(const SweepArgs& a, GemmAcc<TM, TN>& acc, int rt, int ct, int ty) {
     using Cfg = GemmCfg<TM, TN>;
-    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
     const int npad = a.w.npad, Kpad = a.w.Kpad;
-    const int row_tiles = npad / TM;
-    const int rt = blockIdx.x % row_tiles;
-    const int ct = blockIdx.x / row_tiles;
-    const int ty = blockIdx.y;  // column type (mode 0) or generator index (mode 1)
-    if (a.mode == 0 && !a.w.active[(ct * TN) / a.w.TN]) return;
-    const int64_t nn = (int64_t)npad * npad;
     const int64_t typesz = (int64_t)Kpad * npad;
-    const int m = a.B.m;
-
-    GemmAcc<TM, TN> acc;
-    acc.zero();
-    if (a.mode == 0) {
-        const double* Bt = a.Zin + ty * typesz + (int64_t)ct * TN * npad;
-        for (int j = 0; j <= m; ++j)
-            gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, Bt, npad, npad,
-                                    a.w.scaleA + (int64_t)j * Kpad + ct * TN, smem);
-        const TypeDesc td = a.ty.t[ty];
-        for (int e = 0; e < td.n_extra; ++e) {
-            const double* Bs = a.Zin + td.src[e] * typesz + (int64_t)ct * TN * npad;
-            // scaleE[0] carries dt/q, scaleE[1] carries 2 dt/q (the i == j second-order terms)
-            gemm_accumulate<TM, TN>(acc, a.G + (int64_t)td.gen[e] * nn + (int64_t)rt * TM, npad, Bs, npad, npad,
-                                    a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
-        }
-    } else if (a.mode == 1) {
-        gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
-                                nullptr, smem);
-    } else {
-        for (int j = 0; j <= m; ++j)
-            gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
-                                    a.w.scaleU + (int64_t)j * Kpad + ct * TN, smem);
-    }
-
     GemmCoord<TM, TN> co;
     const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
     if (a.mode != 0) {
@@ -785,6 +751,50 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
         }
 }
 
+// One Taylor step of the sweep for every owned interval at once:
+//   term_{t+1}[type] = 1/(t+1) * ( sum_j G_j * (term_t[type] .* dt ubar_j/q)  +  sum_extra G_g * (term_t[src] .* dt/q * mult) )
+// i.e. a GEMM whose K dimension is the concatenation of the generator blocks, the per-interval
+// bilinear coefficients being applied to the B panel while it is staged into LDS.
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(SweepArgs a) {
+    using Cfg = GemmCfg<TM, TN>;
+    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
+    const int npad = a.w.npad, Kpad = a.w.Kpad;
+    const int row_tiles = npad / TM;
+    const int rt = blockIdx.x % row_tiles;
+    const int ct = blockIdx.x / row_tiles;
+    const int ty = blockIdx.y;  // column type (mode 0) or generator index (mode 1)
+    if (a.mode == 0 && !a.w.active[(ct * TN) / a.w.TN]) return;
+    const int64_t nn = (int64_t)npad * npad;
+    const int64_t typesz = (int64_t)Kpad * npad;
+    const int m = a.B.m;
+
+    GemmAcc<TM, TN> acc;
+    acc.zero();
+    if (a.mode == 0) {
+        const double* Bt = a.Zin + ty * typesz + (int64_t)ct * TN * npad;
+        for (int j = 0; j <= m; ++j)
+            gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, Bt, npad, npad,
+                                    a.w.scaleA + (int64_t)j * Kpad + ct * TN, smem);
+        const TypeDesc td = a.ty.t[ty];
+        for (int e = 0; e < td.n_extra; ++e) {
+            const double* Bs = a.Zin + td.src[e] * typesz + (int64_t)ct * TN * npad;
+            // scaleE[0] carries dt/q, scaleE[1] carries 2 dt/q (the i == j second-order terms)
+            gemm_accumulate<TM, TN>(acc, a.G + (int64_t)td.gen[e] * nn + (int64_t)rt * TM, npad, Bs, npad, npad,
+                                    a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
+        }
+    } else if (a.mode == 1) {
+        gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
+                                nullptr, smem);
+    } else {
+        for (int j = 0; j <= m; ++j)
+            gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
+                                    a.w.scaleU + (int64_t)j * Kpad + ct * TN, smem);
+    }
+
+    sweep_epilogue<TM, TN>(a, acc, rt, ct, ty);
+}
+
 static int sweep_tile_choice() {
     static int v = [] { const char* e = getenv("DTO_SWEEP_TILE"); return e ? atoi(e) : -1; }();
     return v;
@@ -809,6 +819,7 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
             hipLaunchKernelGGL((k_sweep<32, 64>), dim3((npad / 32) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
             break;
         case 5:
+            // (a DMA-staged variant of this tile with per-segment accumulators was measured 12 % slower)
             hipLaunchKernelGGL((k_sweep<64, 32>), dim3((npad / 64) * (a.w.Kpad / 32), ny), dim3(256), 0, st, a);
             break;
         default:
