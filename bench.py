@@ -33,32 +33,32 @@ def baseline_metric():
 
 
 def cpu_baseline(n, m, N, budget_s=20.0):
-    """The oracle ("port") timed on the host cores on a bounded sample of the same workload: the
-    bilinear Jacobian blocks (scipy expm + expm_frechet, oracle/dto_oracle.py) of the first knots of
-    the same synthetic problem, until `budget_s` seconds are spent.  BLAS threads = host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
-    import dto_oracle as O
-    import dto_amd
-    G, x, u, du = dto_amd.host.synthetic.scaled_problem_arrays(N, n, m, 42)
-    z = n + 2 * m + 1
-    prob = O.Problem(N=N, z=z, dt_idx=z - 1, integrators=[O.BilinearIntegrator(0, n, n, m, G)], Z0=None)
-    integ = prob.integrators[0]
+    """The oracle ("port") timed on the host cores on a bounded sample of the same workload: W
+    single-threaded worker processes (oracle/cpu_baseline_worker.py; W = the CPUs this process may
+    use, at most 16 = the box's share for one GPU) each evaluate the bilinear Jacobian blocks (scipy
+    expm + expm_frechet, oracle/dto_oracle.py) of every W-th interval of the same synthetic problem
+    until `budget_s` seconds are spent.  Knots are independent, so this is the CPU's parallel rate."""
+    import subprocess
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+        avail = len(os.sched_getaffinity(0))
     except Exception:
-        threads = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    knots = 0
-    while knots < N - 1 and (time.perf_counter() - t0 < budget_s or knots < 2):
-        zk = np.concatenate([x[:, knots], u[:, knots], du[:, knots], [0.1]])
-        O.bilinear_block_jacobian(integ, prob, zk)
-        knots += 1
-    dt = time.perf_counter() - t0
-    return {"value": knots / dt, "unit": "knot-points/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (scipy expm + {m} expm_frechet per knot) on the first {knots} of {N - 1} "
-                      f"intervals of the same problem, {dt:.1f} s, {threads} BLAS threads"}
+        avail = os.cpu_count() or 1
+    W = max(1, min(16, avail, N - 1))
+    worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, worker, ROOT, str(n), str(m), str(N), str(w), str(W), str(budget_s)],
+                              stdout=subprocess.PIPE, env=env, text=True) for w in range(W)]
+    knots, dt = 0, 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=budget_s * 6 + 300)
+        if p.returncode != 0:
+            raise RuntimeError(f"cpu baseline worker exited with {p.returncode}")
+        k, t = out.split()
+        knots += int(k)
+        dt = max(dt, float(t))
+    return {"value": knots / dt, "unit": "knot-points/s", "cores": W, "kind": "port",
+            "sample": f"oracle (scipy expm + {m} expm_frechet per knot), {W} single-threaded processes over "
+                      f"{knots} of the {N - 1} intervals of the same problem, {dt:.1f} s"}
 
 
 def main():

@@ -152,3 +152,20 @@ def test_host_mirror_objects():
     assert isinstance(J, dto_amd.CompositeObjective) and J.weights == [0.5, 1.0]
     with pytest.raises(NotImplementedError):
         dto_amd.NonlinearKnotPointConstraint(lambda u: u, "u", traj)
+
+
+def test_cpu_baseline_worker_uses_the_bench_problem():
+    """oracle/cpu_baseline_worker.py restates the synthetic generator (it must not import the product);
+    both must give the same arrays."""
+    import importlib.util
+    import os
+    import numpy as np
+    import dto_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cpu_baseline_worker", os.path.join(root, "oracle", "cpu_baseline_worker.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    a = W.scaled_problem_arrays(np, 9, 5, 2, 42)
+    b = dto_amd.host.synthetic.scaled_problem_arrays(9, 5, 2, 42)
+    for p, q in zip(a, b):
+        assert np.array_equal(p, q)
