@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 outputs (gpurun_out/...) into the committed summaries under profiles/.
-usage: summarize_profile.py <round tag> <kernel_stats.csv> [<pmc_fetch counter_collection.csv> <pmc_write ...>]"""
+usage: summarize_profile.py <round tag> <kernel_stats.csv> [<pmc_fetch counter_collection.csv> <pmc_write ...> [<pmc_sq ...>]]"""
 import collections
 import csv
 import sys
@@ -32,6 +32,32 @@ def main():
             f = a[1] / max(a[0], 1) / 1024.0
             w = a[3] / max(a[2], 1) / 1024.0
             out.append("| `%s` | %d | %.1f | %.1f | %.1f |" % (k.replace("|", "/"), a[0], f, 2 * f, w))
+    if len(sys.argv) >= 6:
+        names = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+                 "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+        out += ["", "## SQ counters (one `--pmc` pass: " + " ".join(names) + ")", "",
+                "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8); clock = GRBM_GUI_ACTIVE / 8 / duration.", "",
+                "| kernel | launches | avg us | clock GHz | MFMA util | wait_inst/wave | wait_any/wave | LDS conflict/active |",
+                "|---|---|---|---|---|---|---|---|"]
+        disp = {}
+        for r in csv.DictReader(open(sys.argv[5])):
+            d = disp.setdefault(r["Dispatch_Id"], {"k": r["Kernel_Name"][:80], "t": float(r["End_Timestamp"]) - float(r["Start_Timestamp"])})
+            d[r["Counter_Name"]] = float(r["Counter_Value"])
+        agg = collections.OrderedDict()
+        for d in disp.values():
+            if not d["k"].startswith(("void dto", "dto::")):
+                continue
+            a = agg.setdefault(d["k"], collections.Counter())
+            a["n"] += 1
+            a["t"] += d["t"]
+            for nm in names:
+                a[nm] += d.get(nm, 0.0)
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"])[:5]:
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+            out.append("| `%s` | %d | %.1f | %.2f | %.2f | %.2f | %.2f | %.2f |" % (
+                k.replace("|", "/"), a["n"], a["t"] / a["n"] / 1e3, cyc / a["t"], a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc),
+                a["SQ_WAIT_INST_ANY"] / max(a["SQ_WAVE_CYCLES"], 1), a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1),
+                a["SQ_LDS_BANK_CONFLICT"] / max(a["SQ_LDS_IDX_ACTIVE"], 1)))
     print("\n".join(out))
 
 
