@@ -85,6 +85,29 @@ struct ConHost {
     int64_t row_off = 0;  // global 0-based first row
     std::vector<int64_t> times0;  // all times (0-based knots), reference order
     std::vector<int32_t> comps;
+    int g_dim = 1;
+    bool external = false;        // DTO_CONSTRAINT_EXTERNAL: values/Jacobian/Hessian blocks come from dto_set_external
+    int ext_slot = -1;
+    std::vector<double> jac0;     // external: Jacobian blocks at Z0 (pattern)
+};
+
+// DTO_OBJECTIVE_EXTERNAL_KNOT: placement data of a host-evaluated KnotPointObjective
+struct ExtObjHost {
+    int n_comps = 0;
+    double weight = 1.0;
+    int64_t n_times = 0, n_times_total = 0;  // owned / listed
+    int32_t* comps = nullptr;
+    int64_t* times = nullptr;  // owned 0-based knots
+    int64_t* tidx = nullptr;   // their index in the listed times
+    int32_t* last = nullptr;   // 0 where a later listed time names the same knot
+    int ext_slot = -1;
+};
+
+// one host-evaluated term's values for the coming callbacks + grow-only device staging
+struct ExtSlot {
+    dto_external_values v{nullptr, nullptr, nullptr};
+    size_t len[3] = {0, 0, 0};   // doubles per array (all listed times)
+    double* d[3] = {nullptr, nullptr, nullptr};
 };
 
 struct ProfRec {
@@ -115,6 +138,9 @@ struct dto_handle {
     std::vector<int64_t> integ_row_off;
     std::vector<ConHost> con;
     std::vector<KObj> obj;
+    std::vector<ExtObjHost> ext_obj;
+    std::vector<ExtSlot> ext;      // external constraints in list order, then external objectives in list order
+    int n_ext_con = 0, n_ext_obj = 0;
     std::vector<std::pair<int64_t, int64_t>> row_segments;  // (global start 0-based, len)
     int64_t cons_len = 0;
     dto_shard_info info{};
@@ -226,6 +252,12 @@ void build_structure(dto_handle* h, const double* Z0) {
             const int64_t kn = c.times0[i];
             const double* zk = Z0 + kn * h->z;
             for (size_t q = 0; q < c.comps.size(); ++q) {
+                if (c.external) {
+                    for (int r = 0; r < c.g_dim; ++r)
+                        if (c.jac0[((size_t)i * c.comps.size() + q) * c.g_dim + r] != 0.0)
+                            ent.emplace_back(kn * h->z + c.comps[q], c.row_off + i * c.g_dim + r);
+                    continue;
+                }
                 const double v = con_jac_value(c, zk, (int)q);
                 if (v != 0.0) ent.emplace_back(kn * h->z + c.comps[q], c.row_off + i);
             }
@@ -645,14 +677,32 @@ SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st)
 // callbacks (device-pointer forms)
 // ------------------------------------------------------------------------------------------
 
+// copy one of the caller's arrays of an external term (dto_set_external) into its device staging buffer
+const double* ext_upload(dto_handle* h, int slot, int which, hipStream_t st) {
+    ExtSlot& e = h->ext[slot];
+    const double* src = which == 0 ? e.v.values : which == 1 ? e.v.first : e.v.second;
+    static const char* what[3] = {"values", "first-derivative blocks", "second-derivative blocks"};
+    if (!src)
+        throw HipError{"external term " + std::to_string(slot) + ": " + what[which] +
+                       " were not supplied (dto_set_external) -- the engine has no host fallback for closures"};
+    if (!e.d[which]) e.d[which] = own(h, dalloc<double>(e.len[which]));
+    HIP_CHECK(hipMemcpyAsync(e.d[which], src, e.len[which] * sizeof(double), hipMemcpyHostToDevice, st));
+    return e.d[which];
+}
+
 void do_objective(dto_handle* h, const double* dZ, double* df, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(df, 0, sizeof(double), st));
     for (auto& o : h->obj) launch_objective(st, h->P, o, dZ, h->d_partial, df);
+    for (auto& e : h->ext_obj)
+        if (e.n_times > 0) launch_ext_objective(st, e.tidx, e.n_times, e.weight, ext_upload(h, e.ext_slot, 0, st), df);
 }
 
 void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(dgrad, 0, sizeof(double) * (size_t)h->info.grad_len, st));
     for (auto& o : h->obj) launch_gradient(st, h->P, o, dZ, dgrad);
+    for (auto& e : h->ext_obj)
+        if (e.n_times > 0)
+            launch_ext_gradient(st, h->P, e.n_comps, e.comps, e.times, e.tidx, e.last, e.n_times, e.weight, ext_upload(h, e.ext_slot, 1, st), dgrad);
 }
 
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
@@ -669,7 +719,10 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
         }
     }
     for (auto& d : h->der) launch_cons_derivative(st, h->P, d, dZ, dg);
-    for (auto& c : h->con) launch_cons_knot(st, h->P, c.k, dZ, dg);
+    for (auto& c : h->con) {
+        if (!c.external) launch_cons_knot(st, h->P, c.k, dZ, dg);
+        else if (c.k.n_times > 0) launch_ext_cons(st, c.k, ext_upload(h, c.ext_slot, 0, st), dg);
+    }
 }
 
 void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st) {
@@ -708,7 +761,10 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
         launch_jac_bilinear(st, h->P, b.k, b.fw, dvals);
     }
     for (auto& d : h->der) launch_jac_derivative(st, h->P, d, dZ, dvals);
-    for (auto& c : h->con) launch_jac_knot(st, h->P, c.k, dZ, dvals);
+    for (auto& c : h->con) {
+        if (!c.external) launch_jac_knot(st, h->P, c.k, dZ, dvals);
+        else if (c.k.n_times > 0) launch_ext_jac(st, c.k, ext_upload(h, c.ext_slot, 1, st), dvals);
+    }
 }
 
 void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dH, hipStream_t st) {
@@ -750,9 +806,19 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
         }
     }
-    for (auto& c : h->con) launch_hess_knot(st, h->P, c.k, dZ, dmu, dH);
-    if (sigma != 0.0)
+    for (auto& c : h->con) {
+        if (!c.external) launch_hess_knot(st, h->P, c.k, dZ, dmu, dH);
+        else if (c.k.n_times > 0)  // the caller's blocks already carry mu_i (knot_point_constraint.jl:283-291)
+            launch_ext_hess(st, h->P, c.k.n_comps, c.k.comps, c.k.times, c.k.tidx, c.k.hess_on, c.k.n_times, 1.0,
+                            ext_upload(h, c.ext_slot, 2, st), dH);
+    }
+    if (sigma != 0.0) {
         for (auto& o : h->obj) launch_hess_objective(st, h->P, o, dZ, sigma, dH);
+        for (auto& e : h->ext_obj)
+            if (e.n_times > 0)
+                launch_ext_hess(st, h->P, e.n_comps, e.comps, e.times, e.tidx, e.last, e.n_times, sigma * e.weight,
+                                ext_upload(h, e.ext_slot, 2, st), dH);
+    }
 }
 
 double* staging(dto_handle* h, size_t n) {
@@ -904,12 +970,22 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         // nonlinear knot constraints: rows follow the dynamics (evaluator.jl:219-223)
         for (int i = 0; i < d->n_constraints; ++i) {
             const dto_constraint_desc& s = d->constraints[i];
-            if (s.kind != DTO_CONSTRAINT_NORM_MINUS_C && s.kind != DTO_CONSTRAINT_SQNORM_MINUS_C)
-                throw HipError{"unknown constraint kind (closure-based constraints stay on the host)"};
+            if (s.kind != DTO_CONSTRAINT_NORM_MINUS_C && s.kind != DTO_CONSTRAINT_SQNORM_MINUS_C && s.kind != DTO_CONSTRAINT_EXTERNAL)
+                throw HipError{"unknown constraint kind"};
             if (s.n_comps < 1 || !s.comps || (!s.times && s.n_times > 0)) throw HipError{"constraint: bad description"};
             ConHost c;
             c.k.kind = s.kind; c.k.n_comps = s.n_comps; c.k.c = s.c;
             c.equality = s.equality;
+            if (s.kind == DTO_CONSTRAINT_EXTERNAL) {
+                if (s.g_dim < 1) throw HipError{"external constraint: g_dim must be >= 1"};
+                if (!s.jac0) throw HipError{"external constraint: jac0 (Jacobian blocks at Z0) is required for the sparsity pattern"};
+                c.external = true;
+                c.g_dim = s.g_dim;
+                c.jac0.assign(s.jac0, s.jac0 + (size_t)s.g_dim * s.n_comps * s.n_times);
+            } else if (s.g_dim > 1) {
+                throw HipError{"constraint: the built-in kinds have g_dim = 1"};
+            }
+            c.k.g_dim = c.g_dim; c.k.external = c.external ? 1 : 0;
             c.comps.assign(s.comps, s.comps + s.n_comps);
             for (int q : c.comps)
                 if (q < 0 || q >= d->z) throw HipError{"constraint: component out of range"};
@@ -919,10 +995,20 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 c.times0.push_back(s.times[t] - 1);
             }
             c.row_off = row;
-            row += s.n_times;  // g_dim = 1
+            row += s.n_times * c.g_dim;
             h->con.push_back(std::move(c));
         }
         h->n_cons = row;
+        for (auto& c : h->con)
+            if (c.external) {
+                c.ext_slot = (int)h->ext.size();
+                ExtSlot e;
+                e.len[0] = (size_t)c.g_dim * c.n_times_total;
+                e.len[1] = (size_t)c.g_dim * c.comps.size() * c.n_times_total;
+                e.len[2] = c.comps.size() * c.comps.size() * (size_t)c.n_times_total;
+                h->ext.push_back(e);
+            }
+        h->n_ext_con = (int)h->ext.size();
 
         // shard
         KProb& P = h->P;
@@ -966,12 +1052,13 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 const int64_t kn = c.times0[i];
                 if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
                 if (!h->row_segments.empty() && !times.empty() && tidx.back() == i - 1 &&
-                    h->row_segments.back().first + h->row_segments.back().second == c.row_off + i)
-                    h->row_segments.back().second += 1;
+                    h->row_segments.back().first + h->row_segments.back().second == c.row_off + i * c.g_dim)
+                    h->row_segments.back().second += c.g_dim;
                 else
-                    h->row_segments.emplace_back(c.row_off + i, 1);
+                    h->row_segments.emplace_back(c.row_off + i * c.g_dim, c.g_dim);
                 times.push_back(kn);
-                lrows.push_back(lrow++);
+                lrows.push_back(lrow);
+                lrow += c.g_dim;
                 tidx.push_back(i);
                 {
                     int32_t last = 1;
@@ -981,14 +1068,16 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 }
                 for (size_t q = 0; q < c.comps.size(); ++q) {
                     const int64_t col = kn * h->z + c.comps[q];
-                    int64_t pos = -1;
                     const size_t lo = con_lower(h, col);
-                    for (size_t e = lo; e < h->con_cols.size() && h->con_cols[e] == col; ++e)
-                        if (h->con_rows[e] == c.row_off + i) {
-                            pos = h->colptr[col] + (int64_t)h->D * col_cnt(h, kn) + (int64_t)(e - lo) - P.jac_lo;
-                            break;
-                        }
-                    jpos.push_back(pos);
+                    for (int r = 0; r < c.g_dim; ++r) {
+                        int64_t pos = -1;
+                        for (size_t e = lo; e < h->con_cols.size() && h->con_cols[e] == col; ++e)
+                            if (h->con_rows[e] == c.row_off + i * c.g_dim + r) {
+                                pos = h->colptr[col] + (int64_t)h->D * col_cnt(h, kn) + (int64_t)(e - lo) - P.jac_lo;
+                                break;
+                            }
+                        jpos.push_back(pos);
+                    }
                 }
             }
             c.k.n_times = (int64_t)times.size();
@@ -1007,6 +1096,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         I.n_row_segments = (int32_t)h->row_segments.size();
 
         // objectives
+        for (int i = 0; i < d->n_objectives; ++i)
+            if (d->objectives[i].kind == DTO_OBJECTIVE_EXTERNAL_KNOT) h->n_ext_obj++;
         for (int i = 0; i < d->n_objectives && !sonly; ++i) {
             const dto_objective_desc& s = d->objectives[i];
             KObj o{};
@@ -1057,8 +1148,41 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 o.Qs = own(h, dupload(Qs));
                 o.last = own(h, dupload(last));
                 o.params = s.params ? own(h, dupload(params)) : nullptr;
+            } else if (s.kind == DTO_OBJECTIVE_EXTERNAL_KNOT) {
+                if (s.n_comps < 1 || !s.comps || !s.times) throw HipError{"external knot objective: comps and times are required"};
+                std::vector<int32_t> comps(s.comps, s.comps + s.n_comps);
+                for (int q : comps)
+                    if (q < 0 || q >= d->z) throw HipError{"external knot objective: component out of range"};
+                std::vector<int64_t> tix;
+                std::vector<int32_t> last;
+                for (int64_t t = 0; t < s.n_times; ++t) {
+                    if (s.times[t] < 1 || s.times[t] > d->N) throw HipError{"objective: time out of range"};
+                    const int64_t kn = s.times[t] - 1;
+                    if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
+                    times.push_back(kn);
+                    tix.push_back(t);
+                    int32_t is_last = 1;
+                    for (int64_t t2 = t + 1; t2 < s.n_times; ++t2)
+                        if (s.times[t2] == s.times[t]) { is_last = 0; break; }
+                    last.push_back(is_last);
+                }
+                ExtObjHost e;
+                e.n_comps = s.n_comps; e.weight = s.weight;
+                e.n_times = (int64_t)times.size(); e.n_times_total = s.n_times;
+                e.comps = own(h, dupload(comps));
+                e.times = own(h, dupload(times));
+                e.tidx = own(h, dupload(tix));
+                e.last = own(h, dupload(last));
+                e.ext_slot = (int)h->ext.size();
+                ExtSlot sl;
+                sl.len[0] = (size_t)s.n_times;
+                sl.len[1] = (size_t)s.n_comps * s.n_times;
+                sl.len[2] = (size_t)s.n_comps * s.n_comps * s.n_times;
+                h->ext.push_back(sl);
+                h->ext_obj.push_back(e);
+                continue;
             } else {
-                throw HipError{"unknown objective kind (closure-based objectives stay on the host)"};
+                throw HipError{"unknown objective kind"};
             }
             o.n_times = (int64_t)times.size();
             o.times = own(h, dupload(times));
@@ -1239,7 +1363,21 @@ int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper) {
     for (int64_t i = 0; i < h->n_cons; ++i) { lower[i] = 0.0; upper[i] = 0.0; }
     for (auto& c : h->con)
         if (!c.equality)
-            for (int64_t i = 0; i < c.n_times_total; ++i) lower[c.row_off + i] = -std::numeric_limits<double>::infinity();
+            for (int64_t i = 0; i < c.n_times_total * c.g_dim; ++i) lower[c.row_off + i] = -std::numeric_limits<double>::infinity();
+    return 0;
+}
+
+int dto_num_external(const dto_handle* h, int32_t* n_constraints, int32_t* n_objectives) {
+    if (!h) return 1;
+    if (n_constraints) *n_constraints = h->n_ext_con;
+    if (n_objectives) *n_objectives = h->n_ext_obj;
+    return 0;
+}
+int dto_set_external(dto_handle* h, int32_t n, const dto_external_values* v) {
+    if (!h) return 1;
+    if (n != h->n_ext_con + h->n_ext_obj || (n > 0 && !v))
+        return fail(h, "dto_set_external: one entry per external term is required (constraints, then objectives)");
+    for (int i = 0; i < n && i < (int)h->ext.size(); ++i) h->ext[i].v = v[i];
     return 0;
 }
 
@@ -1347,6 +1485,7 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
     if (h->k_lo != 1 || h->k_hi != h->N) throw HipError{"Jacobian-vector products need an unsharded handle"};
     bool mfree = h->eval_hessian != 0 || transpose == 0;  // the adjoint sweep buffers exist only with eval_hessian
     for (auto& b : h->bil) mfree = mfree && !b.small && (transpose == 0 || b.ad.S != nullptr) && b.k.m + 2 <= MAX_TYPES;
+    for (auto& c : h->con) mfree = mfree && !c.external;  // external blocks are placed into the value slab
     static const bool mfree_on = [] { const char* e = getenv("DTO_JV_MATRIX_FREE"); return !e || atoi(e) != 0; }();
     if (mfree && mfree_on) {
         const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;

@@ -166,11 +166,22 @@ struct KCon {  // NonlinearKnotPointConstraint with a built-in g
     const int64_t* tidx;     // device, index of each owned time inside the constraint's full `times`
     const int32_t* hess_on;  // device, 0 where a LATER entry of `times` names the same knot: the reference's
                              // ForwardDiff.hessian! into the block view overwrites (knot_point_constraint.jl:285-291)
+    int32_t g_dim, external; // outputs per listed time (1 for the built-in kinds); external: values come from the host
 };
 void launch_cons_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* g);
 void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* w, double* y, int transpose);
 void launch_jac_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* vals);
 void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* dmu, double* H);
+
+// host-evaluated knot terms (DTO_CONSTRAINT_EXTERNAL / DTO_OBJECTIVE_EXTERNAL_KNOT): scatter of caller-supplied blocks
+void launch_ext_cons(hipStream_t st, const KCon& C, const double* vals, double* g);
+void launch_ext_jac(hipStream_t st, const KCon& C, const double* blocks, double* vals);
+// H[pos(kn, comps[a], comps[b])] += scale * block[tidx][a + nc*b] for comps[a] <= comps[b], where on[ti] != 0
+void launch_ext_hess(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
+                     const int32_t* on, int64_t n_times, double scale, const double* blocks, double* H);
+void launch_ext_objective(hipStream_t st, const int64_t* tidx, int64_t n_times, double weight, const double* vals, double* f);
+void launch_ext_gradient(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
+                         const int32_t* on, int64_t n_times, double weight, const double* blocks, double* grad);
 
 struct KObj {  // objective term
     int32_t kind, comp_off, comp_dim, has_baseline;

@@ -1406,6 +1406,91 @@ void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const doubl
     hipLaunchKernelGGL(k_hess_knot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, C, dZ, dmu, H);
 }
 
+// ============================================================================================
+// host-evaluated knot terms: the caller ran the reference's own closures; the
+// engine only places the blocks.  Same placement rules as the built-in kinds above.
+// ============================================================================================
+__global__ void k_ext_cons(KCon C, const double* __restrict__ src, double* __restrict__ g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C.n_times * C.g_dim) return;
+    const int64_t ti = i / C.g_dim;
+    const int r = (int)(i % C.g_dim);
+    g[C.lrow[ti] + r] = src[C.tidx[ti] * C.g_dim + r];
+}
+void launch_ext_cons(hipStream_t st, const KCon& C, const double* vals, double* g) {
+    const int64_t n = C.n_times * C.g_dim;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_ext_cons, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, C, vals, g);
+}
+
+// blocks: [n_times_total] x (g_dim x n_comps column-major); jpos: [n_times][n_comps][g_dim]
+__global__ void k_ext_jac(KCon C, const double* __restrict__ blocks, double* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = C.n_comps * C.g_dim;
+    if (i >= C.n_times * per) return;
+    const int64_t p = C.jpos[i];
+    if (p < 0) return;
+    const int64_t ti = i / per;
+    vals[p] = blocks[C.tidx[ti] * per + (i % per)];
+}
+void launch_ext_jac(hipStream_t st, const KCon& C, const double* blocks, double* vals) {
+    const int64_t n = C.n_times * C.n_comps * C.g_dim;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_ext_jac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, C, blocks, vals);
+}
+
+__global__ void k_ext_hess(KProb P, int nc, const int32_t* __restrict__ comps, const int64_t* __restrict__ times,
+                           const int64_t* __restrict__ tidx, const int32_t* __restrict__ on, int64_t n_times, double scale,
+                           const double* __restrict__ blocks, double* __restrict__ H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc2 = nc * nc;
+    if (i >= n_times * nc2) return;
+    const int64_t ti = i / nc2;
+    if (!on[ti]) return;
+    const int b = (int)((i % nc2) / nc), a = (int)(i % nc);  // column-major block: element (a, b)
+    const int ca = comps[a], cb = comps[b];
+    if (ca > cb) return;  // row <= col (evaluator.jl:637)
+    const double v = scale * blocks[tidx[ti] * nc2 + (i % nc2)];
+    if (v != 0.0) atomicAdd(&H[hess_pos(P, times[ti], ca, cb)], v);
+}
+void launch_ext_hess(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
+                     const int32_t* on, int64_t n_times, double scale, const double* blocks, double* H) {
+    const int64_t n = n_times * n_comps * n_comps;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_ext_hess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n_comps, comps, times, tidx, on, n_times, scale, blocks, H);
+}
+
+// f += weight * sum of the owned times' values, fixed order within the block (deterministic)
+__global__ void __launch_bounds__(256) k_ext_objective(const int64_t* __restrict__ tidx, int64_t n_times, double weight,
+                                                        const double* __restrict__ vals, double* f) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n_times; i += 256) acc += vals[tidx[i]];
+    const double tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) *f += weight * tot;
+}
+void launch_ext_objective(hipStream_t st, const int64_t* tidx, int64_t n_times, double weight, const double* vals, double* f) {
+    if (n_times <= 0) return;
+    hipLaunchKernelGGL(k_ext_objective, dim3(1), dim3(256), 0, st, tidx, n_times, weight, vals, f);
+}
+
+__global__ void k_ext_gradient(KProb P, int nc, const int32_t* __restrict__ comps, const int64_t* __restrict__ times,
+                               const int64_t* __restrict__ tidx, const int32_t* __restrict__ on, int64_t n_times, double weight,
+                               const double* __restrict__ blocks, double* __restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_times * nc) return;
+    const int64_t ti = i / nc;
+    if (!on[ti]) return;
+    const int c = (int)(i % nc);
+    atomicAdd(&grad[times[ti] * P.z + comps[c] - P.grad_lo], weight * blocks[tidx[ti] * nc + c]);
+}
+void launch_ext_gradient(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
+                         const int32_t* on, int64_t n_times, double weight, const double* blocks, double* grad) {
+    const int64_t n = n_times * n_comps;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_ext_gradient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n_comps, comps, times, tidx, on, n_times, weight, blocks, grad);
+}
+
 // Bilinear block of mu_k' f  (bilinear_integrator.jl:135-161).  With y = exp(A)x, c_j = dexp(A)[dt G_j]x,
 // h_ij = d2exp(A)[dt G_i, dt G_j]x (forward sweep fw), yt = exp(A')mu, ct_j = dexp(A')[dt G_j']mu
 // (adjoint sweep ad), W_j = G_j' mu, Gm = G(u)' mu = sum_j ubar_j W_j:

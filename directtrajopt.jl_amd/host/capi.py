@@ -8,10 +8,10 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 2
+DTO_ABI_VERSION = 3
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE = 1, 2
-OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST = 1, 2, 3, 4
-CONSTRAINT_NORM, CONSTRAINT_SQNORM = 1, 2
+OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT = 1, 2, 3, 4, 5
+CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL = 1, 2, 3
 
 
 class IntegratorDesc(C.Structure):
@@ -27,8 +27,13 @@ class ObjectiveDesc(C.Structure):
 
 
 class ConstraintDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("equality", C.c_int32), ("n_comps", C.c_int32), ("reserved", C.c_int32),
-                ("comps", c_int32_p), ("c", C.c_double), ("times", c_int64_p), ("n_times", C.c_int64)]
+    _fields_ = [("kind", C.c_int32), ("equality", C.c_int32), ("n_comps", C.c_int32), ("g_dim", C.c_int32),
+                ("comps", c_int32_p), ("c", C.c_double), ("times", c_int64_p), ("n_times", C.c_int64),
+                ("jac0", c_double_p)]
+
+
+class ExternalValues(C.Structure):
+    _fields_ = [("values", c_double_p), ("first", c_double_p), ("second", c_double_p)]
 
 
 class ProblemDesc(C.Structure):
@@ -65,6 +70,8 @@ SYMBOLS = {
     "dto_jacobian_structure": (C.c_int, [H, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "dto_hessian_structure": (C.c_int, [H, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "dto_constraint_bounds": (C.c_int, [H, c_double_p, c_double_p]),
+    "dto_num_external": (C.c_int, [H, c_int32_p, c_int32_p]),
+    "dto_set_external": (C.c_int, [H, C.c_int32, C.POINTER(ExternalValues)]),
     "dto_eval_objective": (C.c_int, [H, c_double_p, c_double_p]),
     "dto_eval_gradient": (C.c_int, [H, c_double_p, c_double_p]),
     "dto_eval_constraint": (C.c_int, [H, c_double_p, c_double_p]),

@@ -66,6 +66,7 @@ class Evaluator:
             else:
                 raise NotImplementedError(f"{type(it).__name__} stays on the host (outside the hot-path scope)")
 
+        self._ext_con, self._ext_obj, self._ext_keep = [], [], None
         terms = _flatten_objective(prob.objective)
         objs = (capi.ObjectiveDesc * max(1, len(terms)))()
         for i, (o, w) in enumerate(terms):
@@ -87,6 +88,14 @@ class Evaluator:
                     t = np.ascontiguousarray(o.times, dtype=np.int64)
                     keep.append(t)
                     d.times, d.n_times = _ip(t), t.size
+            elif isinstance(o, KnotPointObjective) and o.external:
+                d.kind = capi.OBJECTIVE_EXTERNAL_KNOT
+                comps = np.ascontiguousarray(o.comps, dtype=np.int32)
+                t = np.ascontiguousarray(o.times, dtype=np.int64)
+                keep += [comps, t]
+                d.comps, d.n_comps = comps.ctypes.data_as(capi.c_int32_p), comps.size
+                d.times, d.n_times = _ip(t), t.size
+                self._ext_obj.append(o)
             elif isinstance(o, KnotPointObjective):
                 d.kind = KnotPointObjective.KINDS[o.kind]
                 comps = np.ascontiguousarray(o.comps, dtype=np.int32)
@@ -105,13 +114,23 @@ class Evaluator:
             objs[i] = d
 
         nl = [c for c in prob.constraints if isinstance(c, NonlinearKnotPointConstraint)]
+        self._nl_constraints = nl
         cons = (capi.ConstraintDesc * max(1, len(nl)))()
         for i, c in enumerate(nl):
             comps = np.ascontiguousarray(c.comps, dtype=np.int32)
             t = np.ascontiguousarray(c.times, dtype=np.int64)
             keep += [comps, t]
-            cons[i] = capi.ConstraintDesc(NonlinearKnotPointConstraint.KINDS[c.kind], int(c.equality), comps.size, 0,
-                                          comps.ctypes.data_as(capi.c_int32_p), c.c, _ip(t), t.size)
+            if c.external:
+                # pattern = the closure's Jacobian at Z0, as the reference takes it (evaluator.jl:136)
+                Zk0 = traj.vec()[:traj.dim * traj.N].reshape(traj.N, traj.dim)
+                jac0 = np.ascontiguousarray(c.external_blocks(Zk0, 1)[1])
+                keep.append(jac0)
+                cons[i] = capi.ConstraintDesc(capi.CONSTRAINT_EXTERNAL, int(c.equality), comps.size, c.g_dim,
+                                              comps.ctypes.data_as(capi.c_int32_p), 0.0, _ip(t), t.size, _dp(jac0))
+                self._ext_con.append(c)
+                continue
+            cons[i] = capi.ConstraintDesc(NonlinearKnotPointConstraint.KINDS[c.kind], int(c.equality), comps.size, 1,
+                                          comps.ctypes.data_as(capi.c_int32_p), c.c, _ip(t), t.size, None)
 
         Z0 = np.ascontiguousarray(traj.vec(), dtype=np.float64)
         desc = capi.ProblemDesc(capi.DTO_ABI_VERSION, device, traj.N, traj.dim, traj.global_dim,
@@ -162,18 +181,60 @@ class Evaluator:
             raise ValueError("Z has the wrong length")
         return Z
 
+    def _stage_external(self, Z, con_need=-1, obj_need=-1, mu=None):
+        """Evaluate the closure-based knot terms on the host (what the Julia shim does with the reference's
+        ForwardDiff code) and hand the blocks to the engine: need 0 = values, 1 = + first derivatives,
+        2 = + second derivatives; -1 = this callback does not read that family."""
+        if not (self._ext_con or self._ext_obj):
+            return
+        if Z is None:
+            raise EngineError("closure-based terms need the host copy of Z (pass Z_host to the *_dev call)")
+        traj = self.trajectory
+        Zk = np.asarray(Z, dtype=np.float64)[:traj.dim * traj.N].reshape(traj.N, traj.dim)
+        vals = (capi.ExternalValues * (len(self._ext_con) + len(self._ext_obj)))()
+        keep = []
+        row = self.n_dynamics_constraints
+        rows = {}
+        for c in self._nl_constraints:
+            rows[id(c)] = row
+            row += c.dim
+        for i, c in enumerate(self._ext_con):
+            if con_need < 0:
+                continue
+            m = None if mu is None else np.asarray(mu, dtype=np.float64)[rows[id(c)]:rows[id(c)] + c.dim]
+            blocks = c.external_blocks(Zk, con_need, m)
+            for name, b in zip(("values", "first", "second"), blocks):
+                if b is not None:
+                    b = np.ascontiguousarray(b, dtype=np.float64)
+                    keep.append(b)
+                    setattr(vals[i], name, _dp(b))
+        for j, o in enumerate(self._ext_obj):
+            if obj_need < 0:
+                continue
+            blocks = o.external_blocks(Zk, obj_need)
+            for name, b in zip(("values", "first", "second"), blocks):
+                if b is not None:
+                    b = np.ascontiguousarray(b, dtype=np.float64)
+                    keep.append(b)
+                    setattr(vals[len(self._ext_con) + j], name, _dp(b))
+        self._ext_keep = (vals, keep)  # the engine reads these host buffers during the next callbacks
+        self._check(self._lib.dto_set_external(self._h, len(vals), vals))
+
     def eval_objective(self, Z):  # evaluator.jl:304
         Z = self._Z(Z)
         f = C.c_double()
+        self._stage_external(Z, obj_need=0)
         self._check(self._lib.dto_eval_objective(self._h, _dp(Z), C.byref(f)))
         return f.value
 
     def eval_objective_gradient(self, grad, Z):  # evaluator.jl:310
         Z = self._Z(Z)
+        self._stage_external(Z, obj_need=1)
         self._check(self._lib.dto_eval_gradient(self._h, _dp(Z), _dp(grad)))
 
     def eval_constraint(self, g, Z):  # evaluator.jl:323
         Z = self._Z(Z)
+        self._stage_external(Z, con_need=0)
         self._check(self._lib.dto_eval_constraint(self._h, _dp(Z), _dp(g)))
 
     def jacobian_structure(self, first=0, count=None):  # evaluator.jl:364 (1-based pairs)
@@ -185,6 +246,7 @@ class Evaluator:
 
     def eval_constraint_jacobian(self, vals, Z):  # evaluator.jl:368
         Z = self._Z(Z)
+        self._stage_external(Z, con_need=1)
         self._check(self._lib.dto_eval_jacobian(self._h, _dp(Z), _dp(vals)))
 
     def hessian_lagrangian_structure(self, first=0, count=None):  # evaluator.jl:385
@@ -197,16 +259,19 @@ class Evaluator:
     def eval_hessian_lagrangian(self, H, Z, sigma, mu):  # evaluator.jl:389
         Z = self._Z(Z)
         mu = np.ascontiguousarray(mu, dtype=np.float64)
+        self._stage_external(Z, con_need=2, obj_need=2 if sigma != 0.0 else -1, mu=mu)
         self._check(self._lib.dto_eval_hessian(self._h, _dp(Z), float(sigma), _dp(mu), _dp(H)))
 
     def eval_constraint_jacobian_product(self, y, Z, w):  # evaluator.jl:406 (y = J w)
         Z = self._Z(Z)
         w = np.ascontiguousarray(w, dtype=np.float64)
+        self._stage_external(Z, con_need=1)
         self._check(self._lib.dto_eval_jacobian_product(self._h, _dp(Z), _dp(w), _dp(y)))
 
     def eval_constraint_jacobian_transpose_product(self, y, Z, w):  # evaluator.jl:432 (y = J' w)
         Z = self._Z(Z)
         w = np.ascontiguousarray(w, dtype=np.float64)
+        self._stage_external(Z, con_need=1)
         self._check(self._lib.dto_eval_jacobian_transpose_product(self._h, _dp(Z), _dp(w), _dp(y)))
 
     def constraint_bounds(self):  # get_nonlinear_constraints, src/solvers/solve.jl:30-65
@@ -223,19 +288,25 @@ class Evaluator:
         return s, ln
 
     # ---- device-resident forms (pointers are integers, e.g. torch.Tensor.data_ptr())
-    def eval_objective_dev(self, dZ, df, stream=0):
+    # (closure-based terms are evaluated on the host: pass the host copy of Z -- and of mu -- as well)
+    def eval_objective_dev(self, dZ, df, stream=0, Z_host=None):
+        self._stage_external(Z_host, obj_need=0)
         self._check(self._lib.dto_eval_objective_dev(self._h, dZ, df, stream))
 
-    def eval_gradient_dev(self, dZ, dgrad, stream=0):
+    def eval_gradient_dev(self, dZ, dgrad, stream=0, Z_host=None):
+        self._stage_external(Z_host, obj_need=1)
         self._check(self._lib.dto_eval_gradient_dev(self._h, dZ, dgrad, stream))
 
-    def eval_constraint_dev(self, dZ, dg, stream=0):
+    def eval_constraint_dev(self, dZ, dg, stream=0, Z_host=None):
+        self._stage_external(Z_host, con_need=0)
         self._check(self._lib.dto_eval_constraint_dev(self._h, dZ, dg, stream))
 
-    def eval_jacobian_dev(self, dZ, dvals, stream=0):
+    def eval_jacobian_dev(self, dZ, dvals, stream=0, Z_host=None):
+        self._stage_external(Z_host, con_need=1)
         self._check(self._lib.dto_eval_jacobian_dev(self._h, dZ, dvals, stream))
 
-    def eval_hessian_dev(self, dZ, sigma, dmu, dvals, stream=0):
+    def eval_hessian_dev(self, dZ, sigma, dmu, dvals, stream=0, Z_host=None, mu_host=None):
+        self._stage_external(Z_host, con_need=2, obj_need=2 if sigma != 0.0 else -1, mu=mu_host)
         self._check(self._lib.dto_eval_hessian_dev(self._h, dZ, float(sigma), dmu, dvals, stream))
 
     # ---- measurement

@@ -1,8 +1,9 @@
 """Host-side mirrors of the reference's hot-path plugin types (same names and argument meaning).
 
-Only the DESCRIPTION lives here; all arithmetic happens in the HIP engine.  Closure-based kinds
-(KnotPointObjective, user g functions, TimeDependentBilinearIntegrator) are outside the hot-path
-scope and raise."""
+Only the DESCRIPTION lives here; all arithmetic of the built-in kinds happens in the HIP engine.
+Closure-based knot terms (a Python callable as the loss / g) are evaluated on the host, as the Julia shim
+does with the reference's own ForwardDiff code, and merged by the engine at its precomputed offsets
+(SURVEY.md §8f rank 2); TimeDependentBilinearIntegrator and the Global* kinds raise."""
 from __future__ import annotations
 
 import numpy as np
@@ -127,25 +128,34 @@ class MinimumTimeObjective(AbstractObjective):
 
 
 class KnotPointObjective(AbstractObjective):
-    """KnotPointObjective(l, names, traj, params; times, Qs) -- src/objectives/knot_point_objectives.jl:65-121,
-    restricted to the engine's built-in loss ``"sqdist"``: l(v, p) = ||v - p||^2 (p = None means zeros, i.e.
-    ``norm(v)^2``).  J = sum_i Q_i l(z_{t_i}[names], p_i)."""
+    """KnotPointObjective(l, names, traj, params; times, Qs) -- src/objectives/knot_point_objectives.jl:65-121.
+    J = sum_i Q_i l(z_{t_i}[names], p_i).
+
+    ``l`` is either the name of a loss built into the engine -- ``"sqdist"``: l(v, p) = ||v - p||^2 (p = None
+    means zeros, i.e. ``norm(v)^2``) -- or a callable ``l(v, p) -> float`` (the reference's closure form).  A
+    callable is evaluated on the host per listed time together with its gradient and Hessian (``grad(v, p)``,
+    ``hess(v, p)`` if given, else differentiated numerically, host/closures.py) and the engine merges the blocks."""
 
     KINDS = {"sqdist": 4}
 
-    def __init__(self, l, names, traj, params=None, times=None, Qs=None):
-        if callable(l):
-            raise NotImplementedError("closure-based losses stay on the host (SURVEY.md §8f rank 2); use a built-in kind")
-        if l not in self.KINDS:
-            raise ValueError(f"unknown built-in loss {l!r}")
+    def __init__(self, l, names, traj, params=None, times=None, Qs=None, grad=None, hess=None):
         names = [names] if isinstance(names, str) else list(names)
+        self.external = callable(l)
+        if not self.external and l not in self.KINDS:
+            raise ValueError(f"unknown built-in loss {l!r}")
         self.kind, self.var_names = l, names
+        self.l, self.grad, self.hess = (l, grad, hess) if self.external else (None, None, None)
         self.times = _times(range(1, traj.N + 1) if times is None else times, traj.N)
         self.comps = np.concatenate([np.asarray(traj.components[n]) for n in names]).astype(np.int32)
         nt = self.times.size
         self.Qs = np.ones(nt) if Qs is None else np.asarray(Qs, dtype=np.float64)
         if self.Qs.shape != (nt,):
             raise ValueError("Qs must have the same length as times")
+        if self.external:
+            self.params = [None] * nt if params is None else list(params)
+            if len(self.params) != nt:
+                raise ValueError("params must have the same length as times")
+            return
         if params is None:
             self.params = None
         else:
@@ -156,32 +166,84 @@ class KnotPointObjective(AbstractObjective):
                 raise ValueError("params must have the same length as times")
             self.params = P
 
+    # host evaluation of a closure-based loss: per listed time Q_i l, Q_i grad l, Q_i hess l
+    def external_blocks(self, Zk, need):
+        from . import closures
+        nt, nc = self.times.size, self.comps.size
+        vals = np.zeros(nt)
+        first = np.zeros((nt, nc)) if need >= 1 else None
+        second = np.zeros((nt, nc, nc)) if need >= 2 else None
+        for i, t in enumerate(self.times):
+            v, p, Q = Zk[t - 1, self.comps], self.params[i], self.Qs[i]
+            vals[i] = Q * float(self.l(v, p))
+            if need >= 1:
+                first[i] = Q * closures.gradient(self.l, v, p, self.grad)
+            if need >= 2:
+                Hm = closures.hessian(lambda x: self.l(x, p), v,
+                                      None if self.grad is None else (lambda x: self.grad(x, p)),
+                                      None if self.hess is None else (lambda x: self.hess(x, p)))
+                second[i] = Q * Hm.T  # column-major block = transpose in C order (symmetric anyway)
+        return vals, first, second
 
-def TerminalObjective(l, names, traj, goal=None, Q=1.0):
+
+def TerminalObjective(l, names, traj, goal=None, Q=1.0, grad=None, hess=None):
     """TerminalObjective(l, name, traj; Q) -- knot_point_objectives.jl:123-157: the loss at the last knot."""
+    if callable(l):
+        return KnotPointObjective(l, names, traj, params=[goal], times=[traj.N], Qs=[float(Q)], grad=grad, hess=hess)
     return KnotPointObjective(l, names, traj, params=None if goal is None else np.asarray(goal, dtype=np.float64)[None, :],
                               times=[traj.N], Qs=[float(Q)])
 
 
 class NonlinearKnotPointConstraint:
-    """NonlinearKnotPointConstraint(g, names, traj; equality, times) --
-    src/constraints/nonlinear/knot_point_constraint.jl:27-107, restricted to the engine's built-in
-    g kinds: ``"norm"`` (g(v) = [||v|| - c], the shape of test/test_snippets.jl:39-45) and
-    ``"sqnorm"`` (g(v) = [||v||^2 - c])."""
+    """NonlinearKnotPointConstraint(g, names, traj; equality, times, params) --
+    src/constraints/nonlinear/knot_point_constraint.jl:27-107.
+
+    ``g`` is either a kind built into the engine -- ``"norm"`` (g(v) = [||v|| - c], the shape of
+    test/test_snippets.jl:39-45) or ``"sqnorm"`` (g(v) = [||v||^2 - c]) -- or a callable ``g(v, p) -> array``
+    (the reference's closure form; g_dim is taken from one evaluation at the trajectory, as the reference does,
+    knot_point_constraint.jl:84-90).  A callable is evaluated on the host together with its Jacobian and the
+    Hessian of mu_i' g (``jac(v, p)``, ``hess(v, p, mu_i)`` if given, else differentiated numerically) and the
+    engine merges the blocks."""
 
     KINDS = {"norm": 1, "sqnorm": 2}
 
-    def __init__(self, g, names, traj, c=0.0, equality=True, times=None):
-        if callable(g):
-            raise NotImplementedError("closure-based g stays on the host (SURVEY.md §8f rank 2); use a built-in kind")
-        if g not in self.KINDS:
-            raise ValueError(f"unknown built-in g kind {g!r}")
+    def __init__(self, g, names, traj, c=0.0, equality=True, times=None, params=None, jac=None, hess=None):
         names = [names] if isinstance(names, str) else list(names)
+        self.external = callable(g)
+        if not self.external and g not in self.KINDS:
+            raise ValueError(f"unknown built-in g kind {g!r}")
         self.kind, self.var_names, self.c, self.equality = g, names, float(c), bool(equality)
         self.times = _times(range(1, traj.N + 1) if times is None else times, traj.N)
         self.comps = np.concatenate([np.asarray(traj.components[n]) for n in names]).astype(np.int32)
         self.g_dim, self.var_dim = 1, self.comps.size
+        if self.external:
+            self.g, self.jac, self.hess = g, jac, hess
+            self.params = [None] * self.times.size if params is None else list(params)
+            if len(self.params) != self.times.size:
+                raise ValueError("params must have the same length as times")
+            Zk = traj.vec()[:traj.dim * traj.N].reshape(traj.N, traj.dim)
+            self.g_dim = int(np.asarray(g(Zk[self.times[0] - 1, self.comps], self.params[0])).size)
         self.dim = self.g_dim * self.times.size
+
+    # host evaluation of a closure-based g: values, Jacobian blocks (column-major g_dim x n_comps), mu-weighted Hessians
+    def external_blocks(self, Zk, need, mu=None):
+        from . import closures
+        nt, nc, gd = self.times.size, self.comps.size, self.g_dim
+        vals = np.zeros((nt, gd))
+        first = np.zeros((nt, nc, gd)) if need >= 1 else None
+        second = np.zeros((nt, nc, nc)) if need >= 2 else None
+        for i, t in enumerate(self.times):
+            v, p = Zk[t - 1, self.comps], self.params[i]
+            vals[i] = np.asarray(self.g(v, p), dtype=np.float64).reshape(gd)
+            if need >= 1:
+                first[i] = closures.jacobian(self.g, v, p, gd, self.jac).T
+            if need >= 2:
+                m = np.asarray(mu[i * gd:(i + 1) * gd], dtype=np.float64)
+                Hm = closures.hessian(lambda x: m @ np.asarray(self.g(x, p)).reshape(gd), v,
+                                      None if self.jac is None else (lambda x: m @ np.asarray(self.jac(x, p)).reshape(gd, nc)),
+                                      None if self.hess is None else (lambda x: self.hess(x, p, m)))
+                second[i] = Hm.T
+        return vals, first, second
 
 
 class DirectTrajOptProblem:

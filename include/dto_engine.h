@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 2
+#define DTO_ABI_VERSION 3
 
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
@@ -43,10 +43,19 @@ extern "C" {
 #define DTO_OBJECTIVE_MINIMUM_TIME 3          /* minimum_time_objective.jl:24-76 */
 #define DTO_OBJECTIVE_KNOT_SQDIST 4           /* KnotPointObjective / TerminalObjective with the built-in loss
                                                  l(v, p) = ||v - p||^2 (knot_point_objectives.jl:65-243) */
+#define DTO_OBJECTIVE_EXTERNAL_KNOT 5         /* KnotPointObjective / TerminalObjective with a HOST closure l: the
+                                                 caller evaluates Q_i l, its gradient and Hessian per listed time
+                                                 (the reference's own ForwardDiff code, knot_point_objectives.jl:
+                                                 173-243) and hands the blocks over with dto_set_external; the
+                                                 engine merges them at its precomputed offsets */
 
 /* built-in g kinds for NonlinearKnotPointConstraint (knot_point_constraint.jl:27-107) */
 #define DTO_CONSTRAINT_NORM_MINUS_C 1   /* g(v) = [ ||v||_2   - c ] */
 #define DTO_CONSTRAINT_SQNORM_MINUS_C 2 /* g(v) = [ ||v||_2^2 - c ] */
+#define DTO_CONSTRAINT_EXTERNAL 3       /* host closure g with g_dim outputs: values, Jacobian blocks and
+                                           mu-weighted Hessian blocks come from the caller (dto_set_external),
+                                           evaluated with the reference's own code (knot_point_constraint.jl:
+                                           235-294); the sparsity pattern is that of `jac0` */
 
 typedef struct dto_integrator_desc {
     int32_t kind;
@@ -81,11 +90,13 @@ typedef struct dto_constraint_desc {
     int32_t kind;
     int32_t equality;       /* 1: g = 0, 0: g <= 0 (src/solvers/solve.jl:54-62) */
     int32_t n_comps;
-    int32_t reserved;
+    int32_t g_dim;          /* outputs per listed time; 0 or 1 for the built-in kinds */
     const int32_t* comps;   /* knot-local component indices (0-based), vcat of var_names comps */
     double c;
     const int64_t* times;   /* 1-based knot indices (required) */
     int64_t n_times;
+    const double* jac0;     /* EXTERNAL only: Jacobian blocks at Z0, [n_times] blocks g_dim x n_comps column-major;
+                               entries that are exactly 0.0 are outside the pattern (evaluator.jl:136) */
 } dto_constraint_desc;
 
 typedef struct dto_problem_desc {
@@ -146,6 +157,26 @@ int dto_jacobian_structure(const dto_handle* h, int64_t first, int64_t count, in
 int dto_hessian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols);
 /* row bounds handed to the solver, src/solvers/solve.jl:30-65: lower/upper per NLP row */
 int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper);
+
+/* Host-evaluated ("external") knot-point terms -- SURVEY.md §8f rank 2.  One entry per EXTERNAL term: the
+ * external constraints in list order, then the external objectives in list order.  All pointers are HOST
+ * pointers; they are read (copied to the device) by every callback that follows until replaced, so the shim
+ * fills whatever the next callback needs and calls dto_set_external first.  Arrays cover ALL listed times of the
+ * term, in list order; a sharded handle reads only the blocks of its own knots.
+ *   constraint: values = g, [n_times] x g_dim;  first = Jacobian blocks, [n_times] x (g_dim x n_comps col-major);
+ *               second = Hessian blocks of mu_i' g, [n_times] x (n_comps x n_comps col-major)
+ *   objective:  values = Q_i l(v_i, p_i), [n_times];  first = Q_i grad l, [n_times] x n_comps;
+ *               second = Q_i Hessian of l, [n_times] x (n_comps x n_comps col-major)
+ * Semantics follow the reference: Jacobian entries are assigned, outside-pattern entries dropped
+ * (evaluator.jl:491-551); gradient!/hessian! overwrite per listed time, so for a knot listed twice the later
+ * block wins; only row <= col Hessian entries are kept (evaluator.jl:637). */
+typedef struct dto_external_values {
+    const double* values;
+    const double* first;
+    const double* second;
+} dto_external_values;
+int dto_num_external(const dto_handle* h, int32_t* n_constraints, int32_t* n_objectives);
+int dto_set_external(dto_handle* h, int32_t n, const dto_external_values* v);
 
 /* host-pointer callbacks (blocking) */
 int dto_eval_objective(dto_handle* h, const double* Z, double* f);                 /* evaluator.jl:304 */

@@ -123,6 +123,41 @@ class KnotConstraint:
 
 
 @dataclass
+class ClosureKnotConstraint:
+    """NonlinearKnotPointConstraint with a user closure g(v, p) of g_dim outputs
+    (src/constraints/nonlinear/knot_point_constraint.jl:27-107, 235-294).  The reference differentiates g
+    with ForwardDiff; the oracle takes the analytic derivatives from the test: jac(v, p) -> (g_dim, d),
+    hess(v, p, mu) -> (d, d) = Hessian of mu' g."""
+
+    g: object
+    jac: object
+    hess: object
+    comps: Sequence[int]
+    times1: Sequence[int]
+    g_dim: int
+    params: Optional[Sequence[object]] = None
+    equality: bool = False
+
+    kind = "closure"
+
+
+@dataclass
+class ClosureKnotObjective:
+    """KnotPointObjective / TerminalObjective with a user closure l(v, p)
+    (src/objectives/knot_point_objectives.jl:65-243); analytic grad(v, p), hess(v, p) from the test."""
+
+    l: object
+    grad: object
+    hess: object
+    comps: Sequence[int]
+    times1: Sequence[int]
+    Qs: Sequence[float]
+    params: Optional[Sequence[object]] = None
+
+    kind = "knot_closure"
+
+
+@dataclass
 class Problem:
     N: int
     z: int  # traj.dim
@@ -130,7 +165,7 @@ class Problem:
     integrators: List[object]
     objectives: List[object] = field(default_factory=list)  # terms
     weights: Optional[List[float]] = None  # composite weights (None: all 1)
-    constraints: List[KnotConstraint] = field(default_factory=list)
+    constraints: List[object] = field(default_factory=list)  # KnotConstraint / ClosureKnotConstraint
     gd: int = 0  # global_dim (columns exist, no hot-path term touches them)
     Z0: Optional[np.ndarray] = None  # initial point (value-dependent constraint patterns)
 
@@ -321,7 +356,13 @@ def integrator_hessian(integ, prob, Z, mu):
 # ----------------------------------------------------------------------------------------------
 
 
-def _g(con, v):
+def _param(term, i):
+    return None if term.params is None else term.params[i]
+
+
+def _g(con, v, i=0):
+    if con.kind == "closure":
+        return np.asarray(con.g(v, _param(con, i)), dtype=np.float64).reshape(con.g_dim)
     if con.kind == "norm":
         return np.array([np.sqrt(v @ v) - con.c])
     if con.kind == "sqnorm":
@@ -329,14 +370,18 @@ def _g(con, v):
     raise ValueError(con.kind)
 
 
-def _g_jac(con, v):
+def _g_jac(con, v, i=0):
+    if con.kind == "closure":
+        return np.asarray(con.jac(v, _param(con, i)), dtype=np.float64).reshape(con.g_dim, len(v))
     if con.kind == "norm":
         return (v / np.sqrt(v @ v))[None, :]
     return (2.0 * v)[None, :]
 
 
-def _g_hess(con, v, mu):
+def _g_hess(con, v, mu, i=0):
     d = len(v)
+    if con.kind == "closure":
+        return np.asarray(con.hess(v, _param(con, i), np.asarray(mu)), dtype=np.float64).reshape(d, d)
     if con.kind == "norm":
         r = np.sqrt(v @ v)
         return mu[0] * (np.eye(d) / r - np.outer(v, v) / r**3)
@@ -349,7 +394,7 @@ def constraint_evaluate(con, prob, Z):
     comps = np.asarray(con.comps)
     for i, t1 in enumerate(con.times1):
         v = _knot(Z, prob, t1 - 1)[comps]
-        out[i * con.g_dim:(i + 1) * con.g_dim] = _g(con, v)
+        out[i * con.g_dim:(i + 1) * con.g_dim] = _g(con, v, i)
     return out
 
 
@@ -359,7 +404,7 @@ def constraint_jacobian(con, prob, Z):
     comps = np.asarray(con.comps)
     for i, t1 in enumerate(con.times1):
         v = _knot(Z, prob, t1 - 1)[comps]
-        Jg = _g_jac(con, v)
+        Jg = _g_jac(con, v, i)
         for r in range(con.g_dim):
             for c, comp in enumerate(comps):
                 if Jg[r, c] != 0.0:
@@ -373,12 +418,11 @@ def constraint_hessian(con, prob, Z, mu):
     comps = np.asarray(con.comps)
     for i, t1 in enumerate(con.times1):
         v = _knot(Z, prob, t1 - 1)[comps]
-        Hg = _g_hess(con, v, mu[i * con.g_dim:(i + 1) * con.g_dim])
+        Hg = _g_hess(con, v, mu[i * con.g_dim:(i + 1) * con.g_dim], i)
         base = (t1 - 1) * prob.z
-        for a, ca in enumerate(comps):
+        for a, ca in enumerate(comps):  # hessian! writes the whole block view: a later listing of the knot overwrites
             for b, cb in enumerate(comps):
-                if Hg[a, b] != 0.0:
-                    H[base + ca, base + cb] = Hg[a, b]
+                H[base + ca, base + cb] = Hg[a, b]
     return H.tocsc()
 
 
@@ -396,6 +440,11 @@ def _baseline(term, t0):
 def term_value(term, prob, Z):
     """objective_value -- regularizers.jl:79-91, :240-249, minimum_time_objective.jl:44-50."""
     J = 0.0
+    if term.kind == "knot_closure":  # knot_point_objectives.jl:173-182
+        comps = np.asarray(term.comps)
+        for i, t1 in enumerate(term.times1):
+            J += term.Qs[i] * float(term.l(_knot(Z, prob, t1 - 1)[comps], _param(term, i)))
+        return J
     if term.kind == "knot_sqdist":  # knot_point_objectives.jl:173-182 (every listed time counts)
         comps = np.asarray(term.comps)
         for i, t1 in enumerate(term.times1):
@@ -421,6 +470,14 @@ def term_value(term, prob, Z):
 
 def term_gradient_accumulate(grad, term, prob, Z, scale=1.0):
     """gradient! (accumulating form) -- regularizers.jl:93-115, :251-271, minimum_time_objective.jl:52-66."""
+    if term.kind == "knot_closure":  # knot_point_objectives.jl:184-207 (per listed time: overwrite, then scale)
+        comps = np.asarray(term.comps)
+        tmp = np.zeros_like(grad)
+        for i, t1 in enumerate(term.times1):
+            v = _knot(Z, prob, t1 - 1)[comps]
+            tmp[(t1 - 1) * prob.z + comps] = term.Qs[i] * np.asarray(term.grad(v, _param(term, i)), dtype=np.float64)
+        grad += scale * tmp
+        return
     if term.kind == "knot_sqdist":
         # gradient! overwrites the knot's view per listed time, then scales (knot_point_objectives.jl:184-207)
         comps = np.asarray(term.comps)
@@ -454,7 +511,7 @@ def term_hessian_structure(term, prob):
     S = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return S.tocsc()
-    if term.kind == "knot_sqdist":  # knot_point_objectives.jl:209-222
+    if term.kind in ("knot_sqdist", "knot_closure"):  # knot_point_objectives.jl:209-222
         comps = np.asarray(term.comps)
         for t1 in term.times1:
             idx = (t1 - 1) * prob.z + comps
@@ -482,6 +539,16 @@ def term_full_hessian(term, prob, Z):
     H = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return H.tocsc()
+    if term.kind == "knot_closure":  # hessian! per listed time (overwrite), triu (knot_point_objectives.jl:224-243)
+        comps = np.asarray(term.comps)
+        for i, t1 in enumerate(term.times1):
+            v = _knot(Z, prob, t1 - 1)[comps]
+            Hl = term.Qs[i] * np.asarray(term.hess(v, _param(term, i)), dtype=np.float64).reshape(len(comps), len(comps))
+            idx = (t1 - 1) * prob.z + comps
+            for a, ia in enumerate(idx):
+                for b, ib in enumerate(idx):
+                    H[ia, ib] = Hl[a, b]
+        return sp.triu(H.tocsc()).tocsc()
     if term.kind == "knot_sqdist":  # hessian! per listed time (overwrite), triu (knot_point_objectives.jl:224-243)
         comps = np.asarray(term.comps)
         for i, t1 in enumerate(term.times1):
@@ -756,6 +823,47 @@ def make_standard_problem(N=10, seed=3, omega=0.1):
         weights=[1.0, 1.0, 1.0, 1.0],
         constraints=[KnotConstraint("norm", [4, 5], 1.0, list(range(2, N)), equality=False)],
         Z0=data.T.reshape(-1).copy())
+
+
+def make_closure_problem(N=9, seed=5):
+    """The standard problem plus closure-based knot terms (the reference's NonlinearKnotPointConstraint /
+    KnotPointObjective take arbitrary closures, knot_point_constraint.jl:27-107, knot_point_objectives.jl:65-121):
+    a 2-output g over (u0, u1, dt) listed at repeated knots, placed BETWEEN two built-in constraints, and a loss over
+    an unsorted component list (x1, du0, x3).  Analytic derivatives stand in for ForwardDiff."""
+    prob = make_standard_problem(N=N, seed=seed)
+    rng = np.random.Generator(np.random.Philox(seed + 100))
+
+    def g(v, p):
+        return np.array([v[0] * v[1] - p[0], np.sin(5.0 * v[2]) + v[0] ** 2 - p[1]])
+
+    def g_jac(v, p):
+        return np.array([[v[1], v[0], 0.0], [2.0 * v[0], 0.0, 5.0 * np.cos(5.0 * v[2])]])
+
+    def g_hess(v, p, mu):
+        return (mu[0] * np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+                + mu[1] * np.array([[2.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, -25.0 * np.sin(5.0 * v[2])]]))
+
+    def l(v, p):
+        return np.exp(v[0]) * v[1] ** 2 + np.cos(v[2] - p[0])
+
+    def l_grad(v, p):
+        e = np.exp(v[0])
+        return np.array([e * v[1] ** 2, 2.0 * e * v[1], -np.sin(v[2] - p[0])])
+
+    def l_hess(v, p):
+        e = np.exp(v[0])
+        return np.array([[e * v[1] ** 2, 2.0 * e * v[1], 0.0], [2.0 * e * v[1], 2.0 * e, 0.0], [0.0, 0.0, -np.cos(v[2] - p[0])]])
+
+    ct = [2, 3, 5, 5, N]
+    closure_con = ClosureKnotConstraint(g, g_jac, g_hess, [4, 5, 10], ct, 2, params=[rng.standard_normal(2) for _ in ct],
+                                        equality=False)
+    prob.constraints = [prob.constraints[0], closure_con,
+                        KnotConstraint("sqnorm", [6, 7], 0.5, [1, N - 1], equality=True)]
+    ot = [1, 4, 4, N]
+    prob.objectives.append(ClosureKnotObjective(l, l_grad, l_hess, [1, 6, 3], ot, list(0.5 + rng.random(len(ot))),
+                                                params=[rng.standard_normal(1) for _ in ot]))
+    prob.weights = list(prob.weights) + [0.7]
+    return prob
 
 
 NAMED_TRAJECTORY_TYPE_1 = np.array([

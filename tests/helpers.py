@@ -5,7 +5,7 @@ import dto_amd
 import dto_oracle as O
 
 
-def to_engine(prob: O.Problem):
+def to_engine(prob: O.Problem, closure_derivatives="numeric"):
     """Build NamedTrajectory + DirectTrajOptProblem (host mirror) describing the same problem."""
     N, z = prob.N, prob.z
     data = prob.Z0[:z * N].reshape(N, z).T
@@ -19,7 +19,7 @@ def to_engine(prob: O.Problem):
         else:
             ranges[(it.xdot_off, it.x_dim)] = None
     for t in prob.objectives:
-        if t.kind not in ("mintime", "knot_sqdist"):
+        if t.kind not in ("mintime", "knot_sqdist", "knot_closure"):
             ranges[(t.comp_off, t.comp_dim)] = None
     ranges[(prob.dt_idx, 1)] = None
     cuts = sorted(ranges)
@@ -53,11 +53,22 @@ def to_engine(prob: O.Problem):
             o = dto_amd.LinearRegularizer(names[(t.comp_off, t.comp_dim)], traj, t.R, times=t.times1)
         elif t.kind == "knot_sqdist":
             o = dto_amd.KnotPointObjective.__new__(dto_amd.KnotPointObjective)
-            o.kind, o.var_names = "sqdist", []
+            o.kind, o.var_names, o.external = "sqdist", [], False
             o.times = np.asarray(t.times1, dtype=np.int64)
             o.comps = np.asarray(t.comps, dtype=np.int32)
             o.Qs = np.asarray(t.Qs, dtype=np.float64)
             o.params = None if t.params is None else np.asarray(t.params, dtype=np.float64)
+        elif t.kind == "knot_closure":
+            # the host mirror differentiates the closure itself (complex step / differences) unless the test
+            # asks for the analytic derivatives to be handed through (closure_derivatives="analytic")
+            o = dto_amd.KnotPointObjective.__new__(dto_amd.KnotPointObjective)
+            o.kind, o.var_names, o.external = t.l, [], True
+            analytic = closure_derivatives == "analytic"
+            o.l, o.grad, o.hess = t.l, (t.grad if analytic else None), (t.hess if analytic else None)
+            o.times = np.asarray(t.times1, dtype=np.int64)
+            o.comps = np.asarray(t.comps, dtype=np.int32)
+            o.Qs = np.asarray(t.Qs, dtype=np.float64)
+            o.params = [None] * o.times.size if t.params is None else list(t.params)
         else:
             o = dto_amd.MinimumTimeObjective(traj, D=t.D)
         terms.append(prob.w(i) * o)
@@ -69,6 +80,18 @@ def to_engine(prob: O.Problem):
     for c in prob.constraints:
         # component indices are passed through a synthetic single name when they form one range
         k = dto_amd.NonlinearKnotPointConstraint.__new__(dto_amd.NonlinearKnotPointConstraint)
+        if c.kind == "closure":
+            analytic = closure_derivatives == "analytic"
+            k.kind, k.var_names, k.c, k.equality, k.external = c.g, [], 0.0, bool(c.equality), True
+            k.g, k.jac, k.hess = c.g, (c.jac if analytic else None), (c.hess if analytic else None)
+            k.times = np.asarray(c.times1, dtype=np.int64)
+            k.comps = np.asarray(c.comps, dtype=np.int32)
+            k.params = [None] * k.times.size if c.params is None else list(c.params)
+            k.g_dim, k.var_dim = c.g_dim, k.comps.size
+            k.dim = k.g_dim * k.times.size
+            cons.append(k)
+            continue
+        k.external = False
         k.kind, k.var_names, k.c, k.equality = c.kind, [], float(c.c), bool(c.equality)
         k.times = np.asarray(c.times1, dtype=np.int64)
         k.comps = np.asarray(c.comps, dtype=np.int32)

@@ -33,9 +33,39 @@ def test_struct_sizes_match_header_layout():
     # sizes computed by hand from include/dto_engine.h (LP64): catches field drift between C and ctypes
     assert ctypes.sizeof(dto_amd.capi.IntegratorDesc) == 32
     assert ctypes.sizeof(dto_amd.capi.ObjectiveDesc) == 96
-    assert ctypes.sizeof(dto_amd.capi.ConstraintDesc) == 48
+    assert ctypes.sizeof(dto_amd.capi.ConstraintDesc) == 56
     assert ctypes.sizeof(dto_amd.capi.ProblemDesc) == 96
     assert ctypes.sizeof(dto_amd.capi.ShardInfo) == 112
+    assert ctypes.sizeof(dto_amd.capi.ExternalValues) == 24
+
+
+def test_struct_layout_matches_the_compiled_header(tmp_path):
+    """sizeof/offsetof of every ABI struct as gcc sees include/dto_engine.h vs the ctypes mirror."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"dto_integrator_desc": dto_amd.capi.IntegratorDesc, "dto_objective_desc": dto_amd.capi.ObjectiveDesc,
+               "dto_constraint_desc": dto_amd.capi.ConstraintDesc, "dto_problem_desc": dto_amd.capi.ProblemDesc,
+               "dto_shard_info": dto_amd.capi.ShardInfo, "dto_external_values": dto_amd.capi.ExternalValues}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dto_engine.h"', 'int main(void) {',
+             'printf("abi %d\\n", DTO_ABI_VERSION);']
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["abi"]) == dto_amd.capi.DTO_ABI_VERSION
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 def test_create_rejects_bad_input():
@@ -66,6 +96,7 @@ PROBLEMS = {
     "standard": lambda: O.make_standard_problem(N=9),
     "type1": lambda: O.make_type1_derivative_problem(),
     "scaled_con": lambda: O.make_scaled_problem(7, 5, 3, seed=8, with_constraint=True),
+    "closure": lambda: O.make_closure_problem(),
 }
 
 
@@ -150,8 +181,32 @@ def test_host_mirror_objects():
     b = dto_amd.MinimumTimeObjective(traj, D=3.0)
     J = 0.5 * (a + 2 * b)
     assert isinstance(J, dto_amd.CompositeObjective) and J.weights == [0.5, 1.0]
-    with pytest.raises(NotImplementedError):
-        dto_amd.NonlinearKnotPointConstraint(lambda u: u, "u", traj)
+    # closure-based knot terms are accepted (host-evaluated, engine-merged); g_dim comes from one evaluation
+    c = dto_amd.NonlinearKnotPointConstraint(lambda u, p: np.array([u[0] ** 2 - 1.0, u[0]]), "u", traj, times=[1, 3])
+    assert c.external and c.g_dim == 2 and c.dim == 4
+    vals, jac, hess = c.external_blocks(traj.vec()[:12].reshape(3, 4), 2, mu=np.array([1.0, 2.0, 3.0, 4.0]))
+    assert np.allclose(vals, [[0.0, 1.0], [0.0, 1.0]]) and np.allclose(jac[:, 0, :], [[2.0, 1.0], [2.0, 1.0]])
+    assert np.allclose(hess[:, 0, 0], [2.0, 6.0], atol=1e-6)  # mu_i[0] * d2(u^2)/du2
+    o = dto_amd.TerminalObjective(lambda x, goal: float(np.sum((x - goal) ** 2)), "x", traj, goal=np.array([1.0, 0.0]), Q=2.0)
+    v, g, _ = o.external_blocks(traj.vec()[:12].reshape(3, 4), 1)
+    assert np.allclose(v, [2.0 * ((2 - 1) ** 2 + 5 ** 2)]) and np.allclose(g, [[4.0, 20.0]])
+    with pytest.raises(ValueError):
+        dto_amd.NonlinearKnotPointConstraint("no-such-kind", "u", traj)
+
+
+def test_external_terms_are_counted_and_required():
+    """dto_num_external / dto_set_external on a structure-only handle (no GPU): slot count and argument check."""
+    p = O.make_closure_problem()
+    ev = dto_amd.Evaluator(to_engine(p), device=-1)
+    nc, no = ctypes.c_int32(), ctypes.c_int32()
+    assert ev._lib.dto_num_external(ev.handle, ctypes.byref(nc), ctypes.byref(no)) == 0
+    assert (nc.value, no.value) == (1, 1)
+    assert ev._lib.dto_set_external(ev.handle, 1, None) != 0  # needs exactly 2 entries
+    vals = (dto_amd.capi.ExternalValues * 2)()
+    assert ev._lib.dto_set_external(ev.handle, 2, vals) == 0
+    lo, hi = ev.constraint_bounds()
+    lo_o, hi_o = O.OracleEvaluator(p).row_bounds()
+    assert np.array_equal(lo, lo_o) and np.array_equal(hi, hi_o)
 
 
 def test_cpu_baseline_worker_uses_the_bench_problem():

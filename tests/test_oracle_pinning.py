@@ -202,3 +202,27 @@ def test_quadratic_regularizer_follows_code_not_docstring():
         d = {(int(r), int(c)): v for r, c, v in zip(hr, hc, H)}
         lo, hi = sorted((v_idx + 1, 2))
         assert (d[(lo, hi)] != 0.0) == keeps
+
+
+def test_closure_terms_pass_the_reference_fd_bars():
+    """Closure-based knot constraint / objective of the oracle (analytic derivatives standing in for ForwardDiff)
+    against finite differences at the reference's own tolerances (evaluator.jl:752, :790)."""
+    p = O.make_closure_problem(N=7)
+    ev = O.OracleEvaluator(p)
+    Z = p.Z0.copy()
+    nv = p.n_vars
+    eps = 1e-6
+    rows, cols = ev.jacobian_structure1()
+    J = np.zeros((ev.n_constraints, nv))
+    J[rows - 1, cols - 1] = ev.eval_constraint_jacobian(Z)
+    Jfd = np.stack([(ev.eval_constraint(Z + eps * e) - ev.eval_constraint(Z - eps * e)) / (2 * eps) for e in np.eye(nv)], axis=1)
+    # a knot listed twice owns two row blocks; both must match
+    assert np.allclose(J, Jfd, atol=1e-6, rtol=1e-6)
+    gfd = np.array([(ev.eval_objective(Z + eps * e) - ev.eval_objective(Z - eps * e)) / (2 * eps) for e in np.eye(nv)])
+    g = ev.eval_objective_gradient(Z)
+    # gradient!/hessian! overwrite per listed time (knot_point_objectives.jl:198): at the knot listed twice the
+    # reference's gradient is that of the LAST listing only, so it differs from the FD of the summed value there
+    dup = [(4 - 1) * p.z + c for c in (1, 6, 3)]
+    keep = np.setdiff1d(np.arange(nv), dup)
+    assert np.allclose(gfd[keep], g[keep], atol=1e-7)
+    assert not np.allclose(gfd[dup], g[dup], atol=1e-3)
