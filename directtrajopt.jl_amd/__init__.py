@@ -22,6 +22,7 @@ from .host.problem import (  # noqa: F401
     CompositeObjective,
     KnotPointObjective,
     TerminalObjective,
+    ket_fidelity_factor,
     NonlinearKnotPointConstraint,
     DirectTrajOptProblem,
 )

@@ -1124,8 +1124,13 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 } else {
                     for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) times.push_back(kn);
                 }
-            } else if (s.kind == DTO_OBJECTIVE_KNOT_SQDIST) {
+            } else if (s.kind == DTO_OBJECTIVE_KNOT_SQDIST || s.kind == DTO_OBJECTIVE_KNOT_LOWRANK_INFIDELITY) {
                 if (s.n_comps < 1 || !s.comps || !s.times) throw HipError{"knot objective: comps and times are required"};
+                if (s.kind == DTO_OBJECTIVE_KNOT_LOWRANK_INFIDELITY) {
+                    if (s.comp_dim < 1 || !s.R) throw HipError{"low-rank infidelity: the factor A (R) and its row count (comp_dim) are required"};
+                    o.comp_dim = s.comp_dim;
+                    o.R = own(h, dupload(std::vector<double>(s.R, s.R + (size_t)s.comp_dim * s.n_comps)));
+                }
                 std::vector<int32_t> comps(s.comps, s.comps + s.n_comps);
                 for (int q : comps)
                     if (q < 0 || q >= d->z) throw HipError{"knot objective: component out of range"};

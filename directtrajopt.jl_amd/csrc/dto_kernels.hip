@@ -1217,6 +1217,18 @@ void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double*
 // ============================================================================================
 
 
+// F = ||A v||^2 of the low-rank infidelity loss, v = z_k[comps]
+__device__ __forceinline__ double lowrank_F(const KObj& O, const double* zk) {
+    double F = 0.0;
+    for (int r = 0; r < O.comp_dim; ++r) {
+        double y = 0.0;
+        for (int c = 0; c < O.n_comps; ++c) y += O.R[r + (int64_t)O.comp_dim * c] * zk[O.comps[c]];
+        F += y * y;
+    }
+    return F;
+}
+__device__ __forceinline__ double sign0(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
+
 // partial[b] = sum over this block's times of the term value
 __global__ void __launch_bounds__(256) k_objective(KProb P, KObj O, const double* __restrict__ Z, double* __restrict__ partial) {
     __shared__ double sm[4];
@@ -1225,7 +1237,9 @@ __global__ void __launch_bounds__(256) k_objective(KProb P, KObj O, const double
         const int64_t kn = O.times[i];
         const double* zk = Z + kn * P.z;
         const double dt = zk[P.dt_idx];
-        if (O.kind == 4) {  // KnotPointObjective, l = ||v - p||^2: sum_i Q_i l (knot_point_objectives.jl:173-182)
+        if (O.kind == 6) {  // l = |1 - ||A v||^2|  (coherent-fidelity loss; A = O.R, k = O.comp_dim rows)
+            acc += O.Qs[i] * fabs(1.0 - lowrank_F(O, zk));
+        } else if (O.kind == 4) {  // KnotPointObjective, l = ||v - p||^2: sum_i Q_i l (knot_point_objectives.jl:173-182)
             double s = 0.0;
             for (int c = 0; c < O.n_comps; ++c) {
                 const double dv = zk[O.comps[c]] - (O.params ? O.params[i * O.n_comps + c] : 0.0);
@@ -1275,7 +1289,19 @@ __global__ void k_gradient(KProb P, KObj O, const double* __restrict__ Z, double
     const double* zk = Z + kn * P.z;
     double* gk = grad + kn * P.z - P.grad_lo;
     const double dt = zk[P.dt_idx];
-    if (O.kind == 4) {  // gradient! writes 2 Q_i (v - p_i) per listed time, later entries overwrite (knot_point_objectives.jl:184-207)
+    if (O.kind == 6) {  // grad l = -2 sign(1 - F) A'(A v); same per-listing overwrite as kind 4
+        if (!O.last[i]) return;
+        const double sgn = sign0(1.0 - lowrank_F(O, zk));
+        for (int c = 0; c < O.n_comps; ++c) {
+            double g = 0.0;
+            for (int r = 0; r < O.comp_dim; ++r) {
+                double y = 0.0;
+                for (int c2 = 0; c2 < O.n_comps; ++c2) y += O.R[r + (int64_t)O.comp_dim * c2] * zk[O.comps[c2]];
+                g += O.R[r + (int64_t)O.comp_dim * c] * y;
+            }
+            atomicAdd(&gk[O.comps[c]], O.weight * O.Qs[i] * (-2.0 * sgn) * g);
+        }
+    } else if (O.kind == 4) {  // gradient! writes 2 Q_i (v - p_i) per listed time, later entries overwrite (knot_point_objectives.jl:184-207)
         if (!O.last[i]) return;
         for (int c = 0; c < O.n_comps; ++c) {
             const double dv = zk[O.comps[c]] - (O.params ? O.params[i * O.n_comps + c] : 0.0);
@@ -1325,7 +1351,19 @@ __global__ void k_hess_objective(KProb P, KObj O, const double* __restrict__ Z, 
     const double* zk = Z + kn * P.z;
     const double dt = zk[P.dt_idx];
     const double sw = sigma * O.weight;
-    if (O.kind == 4) {  // triu of the per-knot Hessian 2 Q_i I (knot_point_objectives.jl:224-243)
+    if (O.kind == 6) {  // A' G A with G = -2 sign(1 - F) I (knot_hvp.jl:58-66), row <= col entries
+        if (!O.last[i]) return;
+        const double sgn = sign0(1.0 - lowrank_F(O, zk));
+        if (sgn == 0.0) return;
+        for (int a = 0; a < O.n_comps; ++a)
+            for (int b = 0; b < O.n_comps; ++b) {
+                const int ca = O.comps[a], cb = O.comps[b];
+                if (ca > cb) continue;
+                double h = 0.0;
+                for (int r = 0; r < O.comp_dim; ++r) h += O.R[r + (int64_t)O.comp_dim * a] * O.R[r + (int64_t)O.comp_dim * b];
+                if (h != 0.0) atomicAdd(&H[hess_pos(P, kn, ca, cb)], sw * O.Qs[i] * (-2.0 * sgn) * h);
+            }
+    } else if (O.kind == 4) {  // triu of the per-knot Hessian 2 Q_i I (knot_point_objectives.jl:224-243)
         if (!O.last[i]) return;
         for (int c = 0; c < O.n_comps; ++c) {
             bool dup = false;  // a component listed twice: hessian of ||v-p||^2 in the concatenated vector maps both onto one entry

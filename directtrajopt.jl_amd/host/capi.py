@@ -10,7 +10,7 @@ c_int32_p = C.POINTER(C.c_int32)
 
 DTO_ABI_VERSION = 3
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE = 1, 2
-OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT = 1, 2, 3, 4, 5
+OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK = 1, 2, 3, 4, 5, 6
 CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL = 1, 2, 3
 
 

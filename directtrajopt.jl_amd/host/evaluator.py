@@ -105,6 +105,10 @@ class Evaluator:
                 d.comps, d.n_comps = comps.ctypes.data_as(capi.c_int32_p), comps.size
                 d.times, d.n_times = _ip(t), t.size
                 d.Qs = _dp(Qs)
+                if getattr(o, "A", None) is not None:
+                    A = np.ascontiguousarray(o.A.T, dtype=np.float64)  # column-major k x n_comps
+                    keep.append(A)
+                    d.R, d.comp_dim = _dp(A), o.A.shape[0]
                 if o.params is not None:
                     P = np.ascontiguousarray(o.params, dtype=np.float64)  # rows = times: column-major n_comps x n_times
                     keep.append(P)

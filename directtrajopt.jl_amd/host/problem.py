@@ -132,13 +132,14 @@ class KnotPointObjective(AbstractObjective):
     J = sum_i Q_i l(z_{t_i}[names], p_i).
 
     ``l`` is either the name of a loss built into the engine -- ``"sqdist"``: l(v, p) = ||v - p||^2 (p = None
-    means zeros, i.e. ``norm(v)^2``) -- or a callable ``l(v, p) -> float`` (the reference's closure form).  A
+    means zeros, i.e. ``norm(v)^2``); ``"lowrank_infidelity"``: l(v) = |1 - ||A v||^2| with the constant factor
+    ``A`` (ket / unitary infidelity in isomorphic coordinates) -- or a callable ``l(v, p) -> float`` (the reference's closure form).  A
     callable is evaluated on the host per listed time together with its gradient and Hessian (``grad(v, p)``,
     ``hess(v, p)`` if given, else differentiated numerically, host/closures.py) and the engine merges the blocks."""
 
-    KINDS = {"sqdist": 4}
+    KINDS = {"sqdist": 4, "lowrank_infidelity": 6}
 
-    def __init__(self, l, names, traj, params=None, times=None, Qs=None, grad=None, hess=None):
+    def __init__(self, l, names, traj, params=None, times=None, Qs=None, grad=None, hess=None, A=None):
         names = [names] if isinstance(names, str) else list(names)
         self.external = callable(l)
         if not self.external and l not in self.KINDS:
@@ -156,6 +157,12 @@ class KnotPointObjective(AbstractObjective):
             if len(self.params) != nt:
                 raise ValueError("params must have the same length as times")
             return
+        self.A = None
+        if l == "lowrank_infidelity":  # l(v) = |1 - ||A v||^2|, knot_hvp.jl:45-84 (ConstantLowRankHVP shape)
+            self.A = np.asarray(A, dtype=np.float64)
+            if self.A.ndim != 2 or self.A.shape[1] != self.comps.size:
+                raise ValueError("A must be a (rank, n_comps) matrix")
+            params = None
         if params is None:
             self.params = None
         else:
@@ -186,10 +193,19 @@ class KnotPointObjective(AbstractObjective):
         return vals, first, second
 
 
-def TerminalObjective(l, names, traj, goal=None, Q=1.0, grad=None, hess=None):
+def ket_fidelity_factor(goal_iso):
+    """A (2 x 2n) with ||A psi~||^2 = |<goal|psi>|^2 for iso vectors psi~ = [Re psi; Im psi]."""
+    g = np.asarray(goal_iso, dtype=np.float64)
+    n = g.size // 2
+    return np.vstack([np.concatenate([g[:n], g[n:]]), np.concatenate([-g[n:], g[:n]])])
+
+
+def TerminalObjective(l, names, traj, goal=None, Q=1.0, grad=None, hess=None, A=None):
     """TerminalObjective(l, name, traj; Q) -- knot_point_objectives.jl:123-157: the loss at the last knot."""
     if callable(l):
         return KnotPointObjective(l, names, traj, params=[goal], times=[traj.N], Qs=[float(Q)], grad=grad, hess=hess)
+    if l == "lowrank_infidelity":
+        return KnotPointObjective(l, names, traj, times=[traj.N], Qs=[float(Q)], A=A)
     return KnotPointObjective(l, names, traj, params=None if goal is None else np.asarray(goal, dtype=np.float64)[None, :],
                               times=[traj.N], Qs=[float(Q)])
 

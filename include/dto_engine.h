@@ -43,6 +43,12 @@ extern "C" {
 #define DTO_OBJECTIVE_MINIMUM_TIME 3          /* minimum_time_objective.jl:24-76 */
 #define DTO_OBJECTIVE_KNOT_SQDIST 4           /* KnotPointObjective / TerminalObjective with the built-in loss
                                                  l(v, p) = ||v - p||^2 (knot_point_objectives.jl:65-243) */
+#define DTO_OBJECTIVE_KNOT_LOWRANK_INFIDELITY 6 /* KnotPointObjective / TerminalObjective with the built-in loss
+                                                 l(v) = |1 - ||A v||^2|, A a constant k x n_comps factor: the
+                                                 coherent (ket / unitary) fidelity losses in isomorphic
+                                                 coordinates, whose per-knot Hessian is the ConstantLowRankHVP
+                                                 shape A' G A with G = -2 sign(1 - F) I (knot_hvp.jl:45-84).
+                                                 A is passed in `R` (k x n_comps column-major), k in `comp_dim` */
 #define DTO_OBJECTIVE_EXTERNAL_KNOT 5         /* KnotPointObjective / TerminalObjective with a HOST closure l: the
                                                  caller evaluates Q_i l, its gradient and Hessian per listed time
                                                  (the reference's own ForwardDiff code, knot_point_objectives.jl:
@@ -74,11 +80,11 @@ typedef struct dto_objective_desc {
     int32_t reserved;
     double weight;          /* CompositeObjective weight (_objectives.jl:106-156) */
     double D;               /* MinimumTimeObjective scale */
-    const double* R;        /* comp_dim weights (regularizers) */
+    const double* R;        /* comp_dim weights (regularizers); LOWRANK_INFIDELITY: the factor A */
     const double* baseline; /* comp_dim x N column-major, or NULL = zeros (QuadraticRegularizer) */
     const int64_t* times;   /* 1-based knot indices, or NULL = 1:N */
     int64_t n_times;
-    /* KNOT_SQDIST only: */
+    /* knot-point kinds (KNOT_SQDIST, KNOT_LOWRANK_INFIDELITY, EXTERNAL_KNOT): */
     const int32_t* comps;   /* knot-local component indices (0-based), vcat of var_names comps */
     int32_t n_comps;
     int32_t reserved2;

@@ -106,6 +106,37 @@ class KnotSqDistObjective:
 
 
 @dataclass
+class LowRankInfidelityObjective:
+    """KnotPointObjective / TerminalObjective with l(v) = |1 - ||A v||^2|, A constant (k x n_comps): the
+    coherent-fidelity losses in isomorphic coordinates.  Its exact Hessian -2 sign(1 - F) A'A is the
+    ConstantLowRankHVP(A, :neg2_sign) shape of src/objectives/knot_hvp.jl:45-84; placement follows
+    knot_point_objectives.jl:173-243 like every KnotPointObjective."""
+
+    comps: Sequence[int]
+    times1: Sequence[int]
+    Qs: Sequence[float]
+    A: np.ndarray
+
+    kind = "knot_lowrank"
+
+
+def as_closure_objective(t: "LowRankInfidelityObjective"):
+    """The same loss as an explicit closure term (what a user of the reference writes)."""
+    A = np.asarray(t.A, dtype=np.float64)
+
+    def l(v, p):
+        return abs(1.0 - float((A @ v) @ (A @ v)))
+
+    def grad(v, p):
+        return -2.0 * np.sign(1.0 - (A @ v) @ (A @ v)) * (A.T @ (A @ v))
+
+    def hess(v, p):
+        return -2.0 * np.sign(1.0 - (A @ v) @ (A @ v)) * (A.T @ A)
+
+    return ClosureKnotObjective(l, grad, hess, list(t.comps), list(t.times1), list(t.Qs), None)
+
+
+@dataclass
 class KnotConstraint:
     """NonlinearKnotPointConstraint with a built-in g (closed set).
 
@@ -440,6 +471,8 @@ def _baseline(term, t0):
 def term_value(term, prob, Z):
     """objective_value -- regularizers.jl:79-91, :240-249, minimum_time_objective.jl:44-50."""
     J = 0.0
+    if term.kind == "knot_lowrank":
+        return term_value(as_closure_objective(term), prob, Z)
     if term.kind == "knot_closure":  # knot_point_objectives.jl:173-182
         comps = np.asarray(term.comps)
         for i, t1 in enumerate(term.times1):
@@ -470,6 +503,8 @@ def term_value(term, prob, Z):
 
 def term_gradient_accumulate(grad, term, prob, Z, scale=1.0):
     """gradient! (accumulating form) -- regularizers.jl:93-115, :251-271, minimum_time_objective.jl:52-66."""
+    if term.kind == "knot_lowrank":
+        return term_gradient_accumulate(grad, as_closure_objective(term), prob, Z, scale)
     if term.kind == "knot_closure":  # knot_point_objectives.jl:184-207 (per listed time: overwrite, then scale)
         comps = np.asarray(term.comps)
         tmp = np.zeros_like(grad)
@@ -511,7 +546,7 @@ def term_hessian_structure(term, prob):
     S = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return S.tocsc()
-    if term.kind in ("knot_sqdist", "knot_closure"):  # knot_point_objectives.jl:209-222
+    if term.kind in ("knot_sqdist", "knot_closure", "knot_lowrank"):  # knot_point_objectives.jl:209-222
         comps = np.asarray(term.comps)
         for t1 in term.times1:
             idx = (t1 - 1) * prob.z + comps
@@ -539,6 +574,8 @@ def term_full_hessian(term, prob, Z):
     H = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return H.tocsc()
+    if term.kind == "knot_lowrank":
+        return term_full_hessian(as_closure_objective(term), prob, Z)
     if term.kind == "knot_closure":  # hessian! per listed time (overwrite), triu (knot_point_objectives.jl:224-243)
         comps = np.asarray(term.comps)
         for i, t1 in enumerate(term.times1):
@@ -823,6 +860,29 @@ def make_standard_problem(N=10, seed=3, omega=0.1):
         weights=[1.0, 1.0, 1.0, 1.0],
         constraints=[KnotConstraint("norm", [4, 5], 1.0, list(range(2, N)), equality=False)],
         Z0=data.T.reshape(-1).copy())
+
+
+def ket_fidelity_factor(goal_iso):
+    """A (2 x 2n) with ||A psi~||^2 = |<goal|psi>|^2 for iso vectors psi~ = [Re psi; Im psi]."""
+    g = np.asarray(goal_iso, dtype=np.float64)
+    n = g.size // 2
+    gr, gi = g[:n], g[n:]
+    return np.vstack([np.concatenate([gr, gi]), np.concatenate([-gi, gr])])
+
+
+def make_ket_problem(N=8, seed=11):
+    """Standard (Pauli) problem with the TerminalObjective replaced by the ket infidelity |1 - |<goal|psi_N>|^2|
+    (x[4] is the iso-vector of a qubit state), plus the same loss listed at interior knots with weights, one knot
+    twice, and a state scaled past F = 1 so that both signs of (1 - F) occur."""
+    prob = make_standard_problem(N=N, seed=seed)
+    goal = np.array([0.6, 0.0, 0.0, 0.8])  # (0.6 + 0i, 0 + 0.8i)
+    A = ket_fidelity_factor(goal)
+    Zk = prob.Z0[:prob.z * N].reshape(N, prob.z)
+    Zk[2, 0:4] = 1.7 * goal  # F = 1.7^2 > 1 at knot 3
+    prob.objectives[0] = LowRankInfidelityObjective([0, 1, 2, 3], [N], [1.0], A)
+    prob.objectives.append(LowRankInfidelityObjective([0, 1, 2, 3], [2, 3, 3, 5], [0.5, 1.5, 0.25, 2.0], A))
+    prob.weights = list(prob.weights) + [0.3]
+    return prob
 
 
 def make_closure_problem(N=9, seed=5):

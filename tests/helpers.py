@@ -19,7 +19,7 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
         else:
             ranges[(it.xdot_off, it.x_dim)] = None
     for t in prob.objectives:
-        if t.kind not in ("mintime", "knot_sqdist", "knot_closure"):
+        if t.kind not in ("mintime", "knot_sqdist", "knot_closure", "knot_lowrank"):
             ranges[(t.comp_off, t.comp_dim)] = None
     ranges[(prob.dt_idx, 1)] = None
     cuts = sorted(ranges)
@@ -53,11 +53,18 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
             o = dto_amd.LinearRegularizer(names[(t.comp_off, t.comp_dim)], traj, t.R, times=t.times1)
         elif t.kind == "knot_sqdist":
             o = dto_amd.KnotPointObjective.__new__(dto_amd.KnotPointObjective)
-            o.kind, o.var_names, o.external = "sqdist", [], False
+            o.kind, o.var_names, o.external, o.A = "sqdist", [], False, None
             o.times = np.asarray(t.times1, dtype=np.int64)
             o.comps = np.asarray(t.comps, dtype=np.int32)
             o.Qs = np.asarray(t.Qs, dtype=np.float64)
             o.params = None if t.params is None else np.asarray(t.params, dtype=np.float64)
+        elif t.kind == "knot_lowrank":
+            o = dto_amd.KnotPointObjective.__new__(dto_amd.KnotPointObjective)
+            o.kind, o.var_names, o.external = "lowrank_infidelity", [], False
+            o.times = np.asarray(t.times1, dtype=np.int64)
+            o.comps = np.asarray(t.comps, dtype=np.int32)
+            o.Qs = np.asarray(t.Qs, dtype=np.float64)
+            o.params, o.A = None, np.asarray(t.A, dtype=np.float64)
         elif t.kind == "knot_closure":
             # the host mirror differentiates the closure itself (complex step / differences) unless the test
             # asks for the analytic derivatives to be handed through (closure_derivatives="analytic")

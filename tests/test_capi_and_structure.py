@@ -97,6 +97,7 @@ PROBLEMS = {
     "type1": lambda: O.make_type1_derivative_problem(),
     "scaled_con": lambda: O.make_scaled_problem(7, 5, 3, seed=8, with_constraint=True),
     "closure": lambda: O.make_closure_problem(),
+    "ket": lambda: O.make_ket_problem(),
 }
 
 

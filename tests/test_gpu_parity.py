@@ -140,3 +140,23 @@ def test_closure_terms_sharded_and_products():
         assert rc != 0 and b"not supplied" in ev._lib.dto_last_error(ev.handle)
     finally:
         ev.close()
+
+
+def test_ket_infidelity_builtin_kind():
+    """the coherent-fidelity loss |1 - ||A v||^2| (ConstantLowRankHVP shape, knot_hvp.jl:45-84) on
+    the device: terminal + weighted interior listings, one knot twice, both signs of (1 - F).  The same problem
+    with the loss written as a host closure must give the same answers through the merge path."""
+    import dto_amd
+    p = O.make_ket_problem()
+    _check(p, tag="ket/builtin")
+    Z = p.Z0 + 0.03 * np.random.default_rng(2).standard_normal(p.n_vars)
+    _check(p, Z=Z, tag="ket/builtin/perturbed")
+    q = O.make_ket_problem()
+    q.objectives = [O.as_closure_objective(t) if t.kind == "knot_lowrank" else t for t in q.objectives]
+    _check(q, Z=Z, tag="ket/closure", closure_derivatives="analytic")
+    # front end: TerminalObjective("lowrank_infidelity", ...) with the factor from a goal state
+    traj = to_engine(p).trajectory
+    A = dto_amd.ket_fidelity_factor([0.6, 0.0, 0.0, 0.8])
+    assert np.array_equal(A, O.ket_fidelity_factor([0.6, 0.0, 0.0, 0.8]))
+    t = dto_amd.TerminalObjective("lowrank_infidelity", "c0", traj, Q=1.0, A=A)
+    assert t.times.tolist() == [p.N] and t.comps.tolist() == [0, 1, 2, 3]

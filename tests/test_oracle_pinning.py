@@ -226,3 +226,26 @@ def test_closure_terms_pass_the_reference_fd_bars():
     keep = np.setdiff1d(np.arange(nv), dup)
     assert np.allclose(gfd[keep], g[keep], atol=1e-7)
     assert not np.allclose(gfd[dup], g[dup], atol=1e-3)
+
+
+def test_ket_infidelity_loss_is_the_fidelity():
+    """|1 - ||A psi~||^2| with A = ket_fidelity_factor(goal) equals 1 - |<goal|psi>|^2 for normalised states, and
+    the oracle's gradient/Hessian of the term match finite differences away from the kink."""
+    rng = np.random.default_rng(4)
+    g = rng.standard_normal(3) + 1j * rng.standard_normal(3)
+    g /= np.linalg.norm(g)
+    psi = rng.standard_normal(3) + 1j * rng.standard_normal(3)
+    psi /= np.linalg.norm(psi)
+    A = O.ket_fidelity_factor(np.concatenate([g.real, g.imag]))
+    v = np.concatenate([psi.real, psi.imag])
+    assert abs(abs(1 - np.sum((A @ v) ** 2)) - (1 - abs(np.vdot(g, psi)) ** 2)) < 1e-14
+    p = O.make_ket_problem(N=6)
+    ev = O.OracleEvaluator(p)
+    Z = p.Z0.copy()
+    eps = 1e-6
+    nv = p.n_vars
+    gfd = np.array([(ev.eval_objective(Z + eps * e) - ev.eval_objective(Z - eps * e)) / (2 * eps) for e in np.eye(nv)])
+    gr = ev.eval_objective_gradient(Z)
+    dup = [(3 - 1) * p.z + c for c in range(4)]  # knot 3 is listed twice: last listing only (knot_point_objectives.jl:198)
+    keep = np.setdiff1d(np.arange(nv), dup)
+    assert np.allclose(gfd[keep], gr[keep], atol=1e-7)
