@@ -793,13 +793,16 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             if (pair) {
                 // (u_i,u_j) block from the stored Taylor terms of the two first-order sweeps (no second-order
                 // columns): E_j * forward terms, Beta-weighted sums of the adjoint terms, then dot products
-                const int nf = steps_f + 1, na = steps_a + 1, T1 = 1 + b.k.m;
-                const int64_t cols = (int64_t)nf * T1 * b.fw.Kpad;
-                {
-                    ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * b.k.m);
-                    launch_apply_generators_cols(st, b.k, b.fw, 0, b.fw.Zt, b.EP, 1, b.k.m, cols);
-                }
+                const int nf = steps_f + 1, na = steps_a + 1, T1 = 1 + b.k.m, m = b.k.m;
+                const int64_t typesz = (int64_t)b.fw.Kpad * b.k.npad;
+                const int64_t cols = (int64_t)nf * b.fw.Kpad;  // the "p" family only: one type of every stored term
                 launch_pair_combine(st, b.ad, T1, nf, na, b.fw.nterms, b.d_Btab, b.Upair);
+                {
+                    ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m * 2.0);
+                    launch_apply_generators_cols(st, b.k, b.fw, 0, b.fw.Zt, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)T1 * typesz);
+                    launch_apply_generators_cols(st, b.k, b.fw, 1, b.Upair, b.EP + (size_t)m * cols * b.k.npad, 1, m, cols,
+                                                 b.fw.Kpad, (int64_t)T1 * typesz);
+                }
                 launch_hess_pair(st, h->P, b.k, b.fw, nf, b.Upair, b.EP, dH);
             }
         } else {
@@ -1225,7 +1228,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 static const bool pair_on = [] { const char* e = getenv("DTO_HESS_PAIRING"); return !e || atoi(e) != 0; }();
                 size_t free_b = 0, total_b = 0;
                 HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-                if (pair_on && m >= 1 && bytes * (3 + m) < 0.4 * (double)free_b) {
+                if (pair_on && m >= 1 && bytes * (3.0 + 2.0 * m / T1) < 0.4 * (double)free_b) {
                     const size_t store = (size_t)dcap * T1 * b.fw.Kpad * b.k.npad;
                     for (SweepBuf* w : {&b.fw, &b.ad}) {
                         w->Zt = own(h, dalloc<double>(store));
@@ -1233,7 +1236,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                         w->nterms = own(h, dalloc<int32_t>(w->Kpad / w->TN));
                         HIP_CHECK(hipMemset(w->nterms, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
                     }
-                    b.EP = own(h, dalloc<double>(store * m));
+                    b.EP = own(h, dalloc<double>((size_t)2 * m * dcap * b.fw.Kpad * b.k.npad));  // G_j p_a and G_j' U^pt_a
                     b.Upair = own(h, dalloc<double>(store));
                     std::vector<double> bt(64 * 64);
                     for (int a = 0; a < 64; ++a)

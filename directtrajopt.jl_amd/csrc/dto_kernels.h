@@ -139,7 +139,8 @@ void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, i
                              double* out);
 // out[g] = G_{gen_first+g} * V over `cols` columns (cols multiple of the sweep tile): the pairing path's E_j * terms
 void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
-                                  double* out, int gen_first, int gen_count, int64_t cols);
+                                  double* out, int gen_first, int gen_count, int64_t cols, int64_t seg_cols = 0,
+                                  int64_t seg_stride = 0);
 // U[a][type][k][:] = sum_b Btab[a][b] * terms[b][type][k][:]   (Beta-function weights of the pairing formula)
 void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int nf_used, int na_used, const int32_t* nterms_f,
                          const double* Btab, double* U);

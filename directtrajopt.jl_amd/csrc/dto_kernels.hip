@@ -695,6 +695,7 @@ struct SweepArgs {
     int mode;            // 0: Taylor step; 1: out_j = G_j V (no sum); 2: out = sum_j ubar_j G_j V
     const double* V;
     double* out;
+    int64_t seg_cols, seg_stride;  // mode 1: V's columns come in segments of seg_cols columns, seg_stride doubles apart (0: contiguous)
 };
 
 // Epilogue shared by the sweep kernels: store the new term, accumulate the sums and the column norms (Taylor
@@ -784,8 +785,9 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
                                     a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
         }
     } else if (a.mode == 1) {
-        gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
-                                nullptr, smem);
+        const int64_t c0 = (int64_t)ct * TN;  // a tile never straddles two segments (seg_cols is a multiple of TN)
+        const double* Vt = a.seg_cols ? a.V + (c0 / a.seg_cols) * a.seg_stride + (c0 % a.seg_cols) * npad : a.V + c0 * npad;
+        gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, Vt, npad, npad, nullptr, smem);
     } else {
         for (int j = 0; j <= m; ++j)
             gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
@@ -841,12 +843,13 @@ void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, i
     launch_sweep_kernel(st, a, B.m + 1);
 }
 void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
-                                  double* out, int gen_first, int gen_count, int64_t cols) {
+                                  double* out, int gen_first, int gen_count, int64_t cols, int64_t seg_cols, int64_t seg_stride) {
     SweepArgs a{};
     a.B = B; a.w = w;
     a.w.Kpad = (int32_t)cols;  // the kernel only uses Kpad as the column count / generator stride in this mode
     a.G = (transposed ? B.GT : B.G) + (int64_t)gen_first * B.npad * B.npad;
     a.mode = 1; a.V = V; a.out = out;
+    a.seg_cols = seg_cols; a.seg_stride = seg_stride;
     launch_sweep_kernel(st, a, gen_count);
 }
 
@@ -887,7 +890,10 @@ void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int nf_used,
 // (u_i, u_j) block of mu_k' f by the pairing formula
 //   d2/du_i du_j [mu' exp(A) x] = sum_{a,b} B(a,b) ( dt~^i_b ' E_j p_a + pt_b ' E_j d^i_a ),  B(a,b) = a! b! / (a+b+1)!
 // (the Taylor terms of exp(tau A)x and exp((1-tau)A')mu integrate against each other over tau in [0,1]);
-// p_a, d^i_a: forward sweep terms, pt_b, dt~^i_b: adjoint sweep terms, U = the b-sums, EP[j] = G_j * forward terms.
+// p_a, d^i_a: forward sweep terms, pt_b, dt~^i_b: adjoint sweep terms, U = the b-sums.  The generators are applied
+// only to the two "p" families:  EP[j]   = G_j  p_a            (first half of EP),
+//                                EP[m+j] = G_j' U^{pt}_a       (second half), so that
+//   sum_b B(a,b) pt_b' E_j d^i_a = (G_j' U^{pt}_a)' d^i_a   needs no product with the d columns.
 __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw, int nf_used, const double* __restrict__ U,
                                                    const double* __restrict__ EP, double* __restrict__ H) {
     __shared__ double red[4][MAX_DRIVES * MAX_DRIVES];
@@ -895,8 +901,8 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
     const int64_t kn = P.kn_lo + kl;
     const int n = B.n, m = B.m, npad = fw.npad, T = 1 + m;
     const int64_t typesz = (int64_t)fw.Kpad * npad;
-    const int64_t tstride = (int64_t)T * typesz;          // one Taylor term of all types
-    const int64_t gstride = (int64_t)nf_used * tstride;   // one generator in EP (cols = nf_used*T*Kpad)
+    const int64_t tstride = (int64_t)T * typesz;          // one Taylor term of all types (U and the stored terms)
+    const int64_t gstride = (int64_t)nf_used * typesz;    // one generator in EP (nf_used terms of one type)
     int nf = fw.nterms[kl / fw.TN];
     if (nf <= 0 || nf > nf_used) nf = nf_used;
     double acc[MAX_DRIVES][MAX_DRIVES];
@@ -906,13 +912,16 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
         const int64_t off = kl * npad + r;
         for (int a = 0; a < nf; ++a) {
             const double* Ua = U + a * tstride + off;
-            const double* Ea = EP + a * tstride + off;
-            const double V = Ua[0];
-            double Ep[MAX_DRIVES];  // G_j p_a: shared by every i
-            for (int j = 0; j < m; ++j) Ep[j] = Ea[j * gstride];
+            const double* Da = fw.Zt + a * tstride + off;
+            const double* Ea = EP + a * typesz + off;
+            double Ep[MAX_DRIVES], Et[MAX_DRIVES];
+            for (int j = 0; j < m; ++j) {
+                Ep[j] = Ea[j * gstride];
+                Et[j] = Ea[(m + j) * gstride];
+            }
             for (int i = 0; i < m; ++i) {
-                const double Ui = Ua[(1 + i) * typesz];
-                for (int j = 0; j < m; ++j) acc[i][j] += Ui * Ep[j] + V * Ea[j * gstride + (1 + i) * typesz];
+                const double Ui = Ua[(1 + i) * typesz], Di = Da[(1 + i) * typesz];
+                for (int j = 0; j < m; ++j) acc[i][j] += Ui * Ep[j] + Et[j] * Di;
             }
         }
     }
