@@ -792,18 +792,17 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
             if (pair) {
                 // (u_i,u_j) block from the stored Taylor terms of the two first-order sweeps (no second-order
-                // columns): E_j * forward terms, Beta-weighted sums of the adjoint terms, then dot products
+                // columns): Beta-weighted sums U_a of the adjoint p terms, G_j' U_a, then dot products with the
+                // forward tangent terms
                 const int nf = steps_f + 1, na = steps_a + 1, T1 = 1 + b.k.m, m = b.k.m;
                 const int64_t typesz = (int64_t)b.fw.Kpad * b.k.npad;
-                const int64_t cols = (int64_t)nf * b.fw.Kpad;  // the "p" family only: one type of every stored term
-                launch_pair_combine(st, b.ad, T1, nf, na, b.fw.nterms, b.d_Btab, b.Upair);
+                const int64_t cols = (int64_t)nf * b.fw.Kpad;  // one type of every stored term
+                launch_pair_combine(st, b.ad, T1, 1, nf, na, b.fw.nterms, b.d_Btab, b.Upair);
                 {
-                    ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m * 2.0);
-                    launch_apply_generators_cols(st, b.k, b.fw, 0, b.fw.Zt, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)T1 * typesz);
-                    launch_apply_generators_cols(st, b.k, b.fw, 1, b.Upair, b.EP + (size_t)m * cols * b.k.npad, 1, m, cols,
-                                                 b.fw.Kpad, (int64_t)T1 * typesz);
+                    ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m);
+                    launch_apply_generators_cols(st, b.k, b.fw, 1, b.Upair, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)T1 * typesz);
                 }
-                launch_hess_pair(st, h->P, b.k, b.fw, nf, b.Upair, b.EP, dH);
+                launch_hess_pair(st, h->P, b.k, b.fw, nf, b.EP, dH);
             }
         } else {
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
@@ -1228,7 +1227,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 static const bool pair_on = [] { const char* e = getenv("DTO_HESS_PAIRING"); return !e || atoi(e) != 0; }();
                 size_t free_b = 0, total_b = 0;
                 HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-                if (pair_on && m >= 1 && bytes * (3.0 + 2.0 * m / T1) < 0.4 * (double)free_b) {
+                if (pair_on && m >= 1 && bytes * (3.0 + 1.0 * m / T1) < 0.4 * (double)free_b) {
                     const size_t store = (size_t)dcap * T1 * b.fw.Kpad * b.k.npad;
                     for (SweepBuf* w : {&b.fw, &b.ad}) {
                         w->Zt = own(h, dalloc<double>(store));
@@ -1236,7 +1235,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                         w->nterms = own(h, dalloc<int32_t>(w->Kpad / w->TN));
                         HIP_CHECK(hipMemset(w->nterms, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
                     }
-                    b.EP = own(h, dalloc<double>((size_t)2 * m * dcap * b.fw.Kpad * b.k.npad));  // G_j p_a and G_j' U^pt_a
+                    b.EP = own(h, dalloc<double>((size_t)m * dcap * b.fw.Kpad * b.k.npad));  // G_j' U_a
                     b.Upair = own(h, dalloc<double>(store));
                     std::vector<double> bt(64 * 64);
                     for (int a = 0; a < 64; ++a)

@@ -142,11 +142,11 @@ void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf&
                                   double* out, int gen_first, int gen_count, int64_t cols, int64_t seg_cols = 0,
                                   int64_t seg_stride = 0);
 // U[a][type][k][:] = sum_b Btab[a][b] * terms[b][type][k][:]   (Beta-function weights of the pairing formula)
-void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int nf_used, int na_used, const int32_t* nterms_f,
-                         const double* Btab, double* U);
+void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int n_types, int nf_used, int na_used,
+                         const int32_t* nterms_f, const double* Btab, double* U);
 // (u_i,u_j) block of the bilinear Hessian from the pairing formula (see k_hess_pair)
-void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* U,
-                      const double* EP, double* H);
+void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* EP,
+                      double* H);
 // GY = sum_j ubar_j G_j (or G_j') * V
 void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V, double* out);
 

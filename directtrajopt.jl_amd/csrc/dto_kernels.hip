@@ -880,29 +880,29 @@ __global__ void __launch_bounds__(256) k_pair_combine(SweepBuf ad, int T, int nf
             if (a0 + q < nf) dst[(a0 + q) * tstride] = acc[q];
     }
 }
-void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int nf_used, int na_used, const int32_t* nterms_f,
-                         const double* Btab, double* U) {
+void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int n_types, int nf_used, int na_used,
+                         const int32_t* nterms_f, const double* Btab, double* U) {
     const int64_t typesz = (int64_t)ad.Kpad * ad.npad;
-    hipLaunchKernelGGL(k_pair_combine, dim3((unsigned)((typesz + 255) / 256), T), dim3(256), 0, st, ad, T, nf_used, na_used,
+    hipLaunchKernelGGL(k_pair_combine, dim3((unsigned)((typesz + 255) / 256), n_types), dim3(256), 0, st, ad, T, nf_used, na_used,
                        nterms_f, Btab, U);
 }
 
-// (u_i, u_j) block of mu_k' f by the pairing formula
-//   d2/du_i du_j [mu' exp(A) x] = sum_{a,b} B(a,b) ( dt~^i_b ' E_j p_a + pt_b ' E_j d^i_a ),  B(a,b) = a! b! / (a+b+1)!
-// (the Taylor terms of exp(tau A)x and exp((1-tau)A')mu integrate against each other over tau in [0,1]);
-// p_a, d^i_a: forward sweep terms, pt_b, dt~^i_b: adjoint sweep terms, U = the b-sums.  The generators are applied
-// only to the two "p" families:  EP[j]   = G_j  p_a            (first half of EP),
-//                                EP[m+j] = G_j' U^{pt}_a       (second half), so that
-//   sum_b B(a,b) pt_b' E_j d^i_a = (G_j' U^{pt}_a)' d^i_a   needs no product with the d columns.
-__global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw, int nf_used, const double* __restrict__ U,
+// (u_i, u_j) block of mu_k' f by the pairing formula.  With p_a, d^i_a the Taylor terms of the forward sweep
+// (exp(A)x and its u_i-tangent) and pt_b those of exp(A')mu,
+//   d2/du_i du_j [mu' exp(A) x] = sum_{a,b} B(a,b) ( pt_b' E_i d^j_a + pt_b' E_j d^i_a ),  B(a,b) = a! b! / (a+b+1)!
+// (split the word mu' ... E ... E ... x at its LEFT generator: what stands to its right is a first-order forward
+// term, what stands to its left a plain adjoint term, and the Taylor terms of exp(tau A) and exp((1-tau)A')
+// integrate against each other over tau in [0,1]).  With U_a = sum_b B(a,b) pt_b (k_pair_combine, type 0 only) and
+// EP[j][a] = G_j' U_a (one generator product per drive and term), the block is  sum_a EP[i][a].d^j_a + EP[j][a].d^i_a.
+__global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw, int nf_used,
                                                    const double* __restrict__ EP, double* __restrict__ H) {
     __shared__ double red[4][MAX_DRIVES * MAX_DRIVES];
     const int64_t kl = blockIdx.x;
     const int64_t kn = P.kn_lo + kl;
     const int n = B.n, m = B.m, npad = fw.npad, T = 1 + m;
     const int64_t typesz = (int64_t)fw.Kpad * npad;
-    const int64_t tstride = (int64_t)T * typesz;          // one Taylor term of all types (U and the stored terms)
-    const int64_t gstride = (int64_t)nf_used * typesz;    // one generator in EP (nf_used terms of one type)
+    const int64_t tstride = (int64_t)T * typesz;          // one stored Taylor term of all forward types
+    const int64_t gstride = (int64_t)nf_used * typesz;    // one generator in EP (nf_used terms)
     int nf = fw.nterms[kl / fw.TN];
     if (nf <= 0 || nf > nf_used) nf = nf_used;
     double acc[MAX_DRIVES][MAX_DRIVES];
@@ -911,23 +911,20 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
     for (int r = threadIdx.x; r < n; r += 256) {
         const int64_t off = kl * npad + r;
         for (int a = 0; a < nf; ++a) {
-            const double* Ua = U + a * tstride + off;
             const double* Da = fw.Zt + a * tstride + off;
             const double* Ea = EP + a * typesz + off;
-            double Ep[MAX_DRIVES], Et[MAX_DRIVES];
+            double Et[MAX_DRIVES], D[MAX_DRIVES];
             for (int j = 0; j < m; ++j) {
-                Ep[j] = Ea[j * gstride];
-                Et[j] = Ea[(m + j) * gstride];
+                Et[j] = Ea[j * gstride];
+                D[j] = Da[(1 + j) * typesz];
             }
-            for (int i = 0; i < m; ++i) {
-                const double Ui = Ua[(1 + i) * typesz], Di = Da[(1 + i) * typesz];
-                for (int j = 0; j < m; ++j) acc[i][j] += Ui * Ep[j] + Et[j] * Di;
-            }
+            for (int i = 0; i < m; ++i)
+                for (int j = i; j < m; ++j) acc[i][j] += Et[i] * D[j] + Et[j] * D[i];
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = 0; i < m; ++i)
-        for (int j = 0; j < m; ++j) {
+        for (int j = i; j < m; ++j) {
             const double v = wave_sum(acc[i][j]);
             if (lane == 0) red[wave][i * MAX_DRIVES + j] = v;
         }
@@ -935,18 +932,16 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
     if (threadIdx.x < m * m) {
         const int i = threadIdx.x / m, j = threadIdx.x % m;
         if (i <= j) {
-            auto tot = [&](int a2, int b2) { return red[0][a2 * MAX_DRIVES + b2] + red[1][a2 * MAX_DRIVES + b2] +
-                                                    red[2][a2 * MAX_DRIVES + b2] + red[3][a2 * MAX_DRIVES + b2]; };
+            const int q = i * MAX_DRIVES + j;
             const double dt = fw.scaleE[kl];  // dt/q with q = 1 on this path
-            const double v = 0.5 * (tot(i, j) + tot(j, i));  // equal in exact arithmetic (mixed partials)
-            hess_add(P, H, kn, B.u_off + i, B.u_off + j, -dt * v);
+            hess_add(P, H, kn, B.u_off + i, B.u_off + j, -dt * (red[0][q] + red[1][q] + red[2][q] + red[3][q]));
         }
     }
 }
-void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* U,
-                      const double* EP, double* H) {
+void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* EP,
+                      double* H) {
     if (P.n_int <= 0) return;
-    hipLaunchKernelGGL(k_hess_pair, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, nf_used, U, EP, H);
+    hipLaunchKernelGGL(k_hess_pair, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, nf_used, EP, H);
 }
 
 void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V, double* out) {
