@@ -304,6 +304,7 @@ int64_t hess_block_start(const dto_handle* h, int64_t kn) {
 void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool adjoint) {
     const int npad = b.k.npad;
     w.npad = npad;
+    w.T_alloc = T;
     w.TN = (npad % 128 == 0) ? 128 : 64;
     int64_t nint = std::max<int64_t>(h->P.n_int, 1);
     w.Kpad = (int)(((nint + w.TN - 1) / w.TN) * w.TN);
@@ -646,16 +647,20 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
         const int nb = (int)std::min<int64_t>(b.chain_cap, nint - c0);
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
-        launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
-        if (b.use_basis) {
-            const int nbpad = ((nb + 127) / 128) * 128;
-            launch_basis_coef(st, h->P, b.k, b.basis[0], dZ, int0, nb, nbpad, nullptr);
-            launch_basis_gemm(st, npad, nb, nbpad, b.basis[0], w.W[1], nullptr);
-        } else {
-            launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]);
-        }
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
-        launch_norm1_one(st, npad, nb, w, 1);
+        if (b.use_basis) {
+            // ||A_k^2||_1 straight from the generator-subspace GEMM's fused column sums: neither A nor A^2 is
+            // written (K = number of degree-2 products: a few GFLOP for all intervals)
+            const int nbpad = ((nb + 127) / 128) * 128;
+            HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * (size_t)nb * npad, st));
+            launch_basis_coef(st, h->P, b.k, b.basis[0], dZ, int0, nb, nbpad, nullptr);
+            launch_basis_gemm(st, npad, nb, nbpad, b.basis[0], nullptr, w.colsum);
+            launch_norm_from_colsum(st, npad, nb, w.colsum, w.norms, 1, w.d2max);
+        } else {
+            launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+            launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]);
+            launch_norm1_one(st, npad, nb, w, 1);
+        }
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
         HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));

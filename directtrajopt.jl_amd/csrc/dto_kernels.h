@@ -113,7 +113,7 @@ struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear i
     int32_t* stats;    // [0] active blocks after the last check, [1] terms used (max)
     // term store (Hessian pairing path): every Taylor term of the sweep is kept, [dcap][T][Kpad][npad]
     double* Zt;
-    int32_t dcap, pad2;
+    int32_t dcap, T_alloc;  // T_alloc: column types the Z/S buffers were sized for
     int32_t* nterms;   // [Kpad/TN] number of valid terms of a converged column block (0: use all launched)
 };
 
@@ -243,7 +243,8 @@ void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals
 // the caller); the exact 1-norms then cost no extra pass over the matrices.
 void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum);
 // norms[b*4 + which] = max_c colsum[b][c]
-void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which);
+void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which,
+                             unsigned long long* d2max = nullptr);
 // out2[0] = max_k min(b1_k, b2_k), out2[1] = max_k b1_k (bit patterns of non-negative doubles), where
 // b1_k >= ||A_k||_1 and b2_k >= ||A_k^2||_1^(1/2) follow from the generator norms g1[j] = ||G_j||_1,
 // n2[i][j] = ||G_i G_j||_1 and the triangle inequality.

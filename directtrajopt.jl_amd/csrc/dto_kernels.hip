@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSe
             double asum = 0.0;
 #pragma unroll
             for (int ti = 0; ti < Cfg::MT; ++ti) {
-                if (col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
+                if (out && col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
                 asum += fabs(acc.v[ti][tj][r]);
             }
             if (colsum) {
@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSe
             }
         }
 }
-__global__ void k_norm_from_colsum(int npad, int nb, const double* __restrict__ colsum, double* __restrict__ norms, int which) {
+__global__ void k_norm_from_colsum(int npad, int nb, const double* __restrict__ colsum, double* __restrict__ norms, int which,
+                                   unsigned long long* d2max) {
     const int b = blockIdx.x;
     double m = 0.0;
     for (int c = threadIdx.x; c < npad; c += 64) m = fmax(m, colsum[(int64_t)b * npad + c]);
@@ -151,10 +152,15 @@ __global__ void k_norm_from_colsum(int npad, int nb, const double* __restrict__ 
     double bad = 0.0;
     for (int c = threadIdx.x; c < npad; c += 64) { const double v = colsum[(int64_t)b * npad + c]; if (!(v == v)) bad = 1.0; }
     bad = wave_max(bad);
-    if (threadIdx.x == 0) norms[b * 4 + which] = bad > 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : m;
+    if (threadIdx.x == 0) {
+        const double v = bad > 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : m;
+        norms[b * 4 + which] = v;
+        if (d2max) atomicMax(d2max, dbits(sqrt(v)));  // a NaN's bit pattern exceeds every finite one
+    }
 }
-void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which) {
-    hipLaunchKernelGGL(k_norm_from_colsum, dim3(nb), dim3(64), 0, st, npad, nb, colsum, norms, which);
+void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which,
+                             unsigned long long* d2max) {
+    hipLaunchKernelGGL(k_norm_from_colsum, dim3(nb), dim3(64), 0, st, npad, nb, colsum, norms, which, d2max);
 }
 void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum) {
     const int64_t nn = (int64_t)npad * npad;
@@ -692,7 +698,8 @@ struct SweepArgs {
     const double* Zin;
     double* Zout;
     int t;               // producing term t+1 from term t
-    int mode;            // 0: Taylor step; 1: out_j = G_j V (no sum); 2: out = sum_j ubar_j G_j V
+    int mode;            // 0: Taylor step; 1: out_j = G_j V (no sum); 2: out = sum_j ubar_j G_j V;
+                         // 3: split-K Taylor step of a single column type: out_j = G_j (V .* dt ubar_j/q), active blocks only
     const double* V;
     double* out;
     int64_t seg_cols, seg_stride;  // mode 1: V's columns come in segments of seg_cols columns, seg_stride doubles apart (0: contiguous)
@@ -708,7 +715,7 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs& a, GemmAcc<TM, T
     GemmCoord<TM, TN> co;
     const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
     if (a.mode != 0) {
-        double* O = a.out + (a.mode == 1 ? ty * typesz : 0);
+        double* O = a.out + (a.mode == 1 || a.mode == 3 ? ty * typesz : 0);
 #pragma unroll
         for (int tj = 0; tj < Cfg::NT; ++tj)
 #pragma unroll
@@ -765,7 +772,7 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
     const int rt = blockIdx.x % row_tiles;
     const int ct = blockIdx.x / row_tiles;
     const int ty = blockIdx.y;  // column type (mode 0) or generator index (mode 1)
-    if (a.mode == 0 && !a.w.active[(ct * TN) / a.w.TN]) return;
+    if ((a.mode == 0 || a.mode == 3) && !a.w.active[(ct * TN) / a.w.TN]) return;
     const int64_t nn = (int64_t)npad * npad;
     const int64_t typesz = (int64_t)Kpad * npad;
     const int m = a.B.m;
@@ -784,6 +791,9 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
             gemm_accumulate<TM, TN>(acc, a.G + (int64_t)td.gen[e] * nn + (int64_t)rt * TM, npad, Bs, npad, npad,
                                     a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
         }
+    } else if (a.mode == 3) {
+        gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
+                                a.w.scaleA + (int64_t)ty * Kpad + ct * TN, smem);
     } else if (a.mode == 1) {
         const int64_t c0 = (int64_t)ct * TN;  // a tile never straddles two segments (seg_cols is a multiple of TN)
         const double* Vt = a.seg_cols ? a.V + (c0 / a.seg_cols) * a.seg_stride + (c0 % a.seg_cols) * npad : a.V + c0 * npad;
@@ -820,6 +830,9 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
         case 4:
             hipLaunchKernelGGL((k_sweep<32, 64>), dim3((npad / 32) * (a.w.Kpad / 64), ny), dim3(256), 0, st, a);
             break;
+        case 6:
+            hipLaunchKernelGGL((k_sweep<32, 32>), dim3((npad / 32) * (a.w.Kpad / 32), ny), dim3(256), 0, st, a);
+            break;
         case 5:
             // (a DMA-staged variant of this tile with per-segment accumulators was measured 12 % slower)
             hipLaunchKernelGGL((k_sweep<64, 32>), dim3((npad / 64) * (a.w.Kpad / 32), ny), dim3(256), 0, st, a);
@@ -829,11 +842,55 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
     }
 }
 
+// Second half of a split-K step: term_{t+1} = 1/(t+1) * sum_g partial_g in fixed order (deterministic), sums and
+// column norms exactly as sweep_epilogue does them.  One workgroup per interval column.
+__global__ void __launch_bounds__(256) k_sweep_finalize(SweepBuf w, double* __restrict__ Zout, const double* __restrict__ part,
+                                                         int m1, int t) {
+    const int col = blockIdx.x;
+    if (!w.active[col / w.TN]) return;
+    __shared__ double sm[8];
+    const int64_t typesz = (int64_t)w.Kpad * w.npad;
+    const double inv = 1.0 / (double)(t + 1);
+    double tmax = 0.0, smax = 0.0;
+    for (int r = threadIdx.x; r < w.npad; r += 256) {
+        const int64_t off = (int64_t)col * w.npad + r;
+        double v = 0.0;
+        for (int g = 0; g < m1; ++g) v += part[g * typesz + off];
+        v *= inv;
+        const double s = w.S[off] + v;
+        Zout[off] = v;
+        w.S[off] = s;
+        tmax = fmax(tmax, fabs(v));
+        smax = fmax(smax, fabs(s));
+    }
+    tmax = wave_max(tmax);
+    smax = wave_max(smax);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = tmax; sm[4 + (threadIdx.x >> 6)] = smax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tmax = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        smax = fmax(fmax(sm[4], sm[5]), fmax(sm[6], sm[7]));
+        w.termnorm[(int64_t)((t + 1) % 3) * w.Kpad + col] = dbits(tmax);  // T = 1
+        const double old = bits_to_d(w.sumnorm[col]);
+        w.sumnorm[col] = dbits(fmax(old, smax));
+    }
+}
+
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed, int t,
                        int in_buf) {
     SweepArgs a{};
     a.B = B; a.w = w; a.ty = ty; a.G = transposed ? B.GT : B.G;
     a.Zin = w.Z[in_buf]; a.Zout = w.Z[in_buf ^ 1]; a.t = t; a.mode = 0;
+    // a single column type (eval_constraint) offers few tiles with a long K loop each: split K by generator into the
+    // unused type slots of the output buffer, then sum the partials (DTO_SWEEP_SPLITK=0 disables)
+    static const bool splitk = [] { const char* e = getenv("DTO_SWEEP_SPLITK"); return !e || atoi(e) != 0; }();
+    if (splitk && ty.T == 1 && B.m >= 1 && w.T_alloc >= B.m + 2 && w.Z[0] != w.Zt && a.Zin != w.Zt) {
+        const int64_t typesz = (int64_t)w.Kpad * w.npad;
+        a.mode = 3; a.V = a.Zin; a.out = a.Zout + typesz;
+        launch_sweep_kernel(st, a, B.m + 1);
+        hipLaunchKernelGGL(k_sweep_finalize, dim3(w.Kpad), dim3(256), 0, st, w, a.Zout, a.Zout + typesz, B.m + 1, t);
+        return;
+    }
     launch_sweep_kernel(st, a, ty.T);
 }
 void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
