@@ -188,6 +188,12 @@ def main():
                 "share_of_step": ms_gemm / (ms_per_step * args.steps) if ms_per_step > 0 else None,
                 "template_instances": variants,
             },
+            # the whole callback against the HBM roofline (BASELINE north_star asks for this fraction too): algorithmic
+            # bytes = mandatory output write + read of Z + one read of the generators
+            "callback_hbm": (lambda nbytes: {"algorithmic_bytes": nbytes, "achieved": nbytes / (ms_per_step * 1e-3) / 1e9,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": nbytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS})(
+                8.0 * (out.numel() + Z.numel() + (m + 1) * n * n + (ev.n_constraints if args.callback == "hessian" else 0))),
             "secondary_kernel": {"kernel": "k_sweep (generator sweep: exp(A)x and its u-tangents)",
                                  "ms_per_step": ms_sweep / args.steps, "launches": n_sweep,
                                  "achieved_tflops": fl_sweep / (ms_sweep * 1e-3) / 1e12 if ms_sweep > 0 else 0.0},

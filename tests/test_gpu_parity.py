@@ -160,3 +160,11 @@ def test_ket_infidelity_builtin_kind():
     assert np.array_equal(A, O.ket_fidelity_factor([0.6, 0.0, 0.0, 0.8]))
     t = dto_amd.TerminalObjective("lowrank_infidelity", "c0", traj, Q=1.0, A=A)
     assert t.times.tolist() == [p.N] and t.comps.tolist() == [0, 1, 2, 3]
+
+
+@pytest.mark.parametrize("n,m,N", [(128, 2, 3), (192, 3, 3), (256, 4, 3)])
+def test_large_state_shapes_against_the_oracle(n, m, N):
+    """The state sizes of BASELINE configs[2..3] (256) and their neighbours, all callbacks incl. the Hessian, on few
+    knots so that the oracle (scipy expm/expm_frechet, block-triangular second-order terms) finishes in seconds:
+    128 and 256 take the generator-subspace powers, 192 (not a multiple of 128) the plain GEMM chain."""
+    _check(O.make_scaled_problem(N, n, m, seed=11), tag=f"large-state n={n}")
