@@ -639,7 +639,9 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
 // max_k ||A_k^2||_1^(1/2), exact, for callbacks that do not run the propagator chain: A_k and A_k^2 only
 // (one streaming pass + one small GEMM per chunk).  Sharper than the generator-norm bound, so the sweep
 // usually needs a single round (q = 1).
-double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
+// `higher`: also ||A^3||, ||A^4|| (store-less basis GEMMs) and return max_k min(d2, max(d3, d4)) -- the sharper growth
+// rate of Al-Mohy & Higham's alpha_3, worth its cost only when d2 alone would force sub-stepping
+double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, bool higher = false) {
     const int npad = b.k.npad;
     const int64_t nint = h->P.n_int;
     double d2max = 0.0;
@@ -652,10 +654,15 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
             // ||A_k^2||_1 straight from the generator-subspace GEMM's fused column sums: neither A nor A^2 is
             // written (K = number of degree-2 products: a few GFLOP for all intervals)
             const int nbpad = ((nb + 127) / 128) * 128;
-            HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * (size_t)nb * npad, st));
-            launch_basis_coef(st, h->P, b.k, b.basis[0], dZ, int0, nb, nbpad, nullptr);
-            launch_basis_gemm(st, npad, nb, nbpad, b.basis[0], nullptr, w.colsum);
-            launch_norm_from_colsum(st, npad, nb, w.colsum, w.norms, 1, w.d2max);
+            const int nr = higher ? 3 : 1;
+            HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * ((size_t)(nr - 1) * b.chain_cap + nb) * npad, st));
+            for (int r = 0; r < nr; ++r) {
+                double* cs = w.colsum + (size_t)r * b.chain_cap * npad;
+                launch_basis_coef(st, h->P, b.k, b.basis[r], dZ, int0, nb, nbpad, nullptr);
+                launch_basis_gemm(st, npad, nb, nbpad, b.basis[r], nullptr, cs);
+                launch_norm_from_colsum(st, npad, nb, cs, w.norms, 1 + r, higher ? nullptr : w.d2max);
+            }
+            if (higher) launch_beta_from_norms(st, nb, w);
         } else {
             launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
             launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]);
@@ -674,7 +681,8 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
 SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
     Bounds bd = get_bounds(h, b, dZ, st);
     if (plan_sweep(bd.beta).q == 1) return plan_sweep(bd.beta);  // the cheap bound already gives one round
-    const double d2 = exact_d2(h, b, dZ, st);
+    double d2 = exact_d2(h, b, dZ, st);
+    if (d2 == d2 && plan_sweep(std::min(bd.beta, d2)).q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);
     return plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
 }
 

@@ -515,6 +515,18 @@ __global__ void __launch_bounds__(256) k_norm1(int npad, ChainWork w, int only) 
         if (only == 1) atomicMax(w.d2max, dbits(sqrt(nrm)));
     }
 }
+// max_k min(d2_k, max(d3_k, d4_k)) from the exact norms of A^2, A^3, A^4 (non-chain callbacks at large norm)
+__global__ void k_beta_from_norms(int nb, ChainWork w) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const double d2v = sqrt(w.norms[b * 4 + 1]), d3v = cbrt(w.norms[b * 4 + 2]), d4v = sqrt(sqrt(w.norms[b * 4 + 3]));
+    double beta = fmin(d2v, fmax(d3v, d4v));
+    if (!(d2v == d2v) || !(d3v == d3v) || !(d4v == d4v)) beta = __longlong_as_double(0x7ff8000000000000ll);
+    atomicMax(w.d2max, dbits(beta));
+}
+void launch_beta_from_norms(hipStream_t st, int nb, const ChainWork& w) {
+    hipLaunchKernelGGL(k_beta_from_norms, dim3((nb + 255) / 256), dim3(256), 0, st, nb, w);
+}
 void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w) {
     hipLaunchKernelGGL(k_norm1, dim3(nb, 4), dim3(256), 0, st, npad, w, -1);
 }
@@ -543,7 +555,10 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     w.s[b] = s;
     atomicMax(&w.smax[0], s);
     atomicAdd(&w.smax[1], s);
-    atomicMax(w.d2max, dbits(d2v));
+    // growth rate handed to the sweep planner: ||A^t|| <= d2^t (t even) and <= max(d3,d4)^t (t >= 6)
+    double beta = fmin(d2v, fmax(d3v, d4v));
+    if (!(d2v == d2v) || !(d3v == d3v) || !(d4v == d4v)) beta = __longlong_as_double(0x7ff8000000000000ll);
+    atomicMax(w.d2max, dbits(beta));
     const double sigma = ldexp(1.0, -s);
     double c = 1.0;
     double* cf = w.coef + (int64_t)b * COEF_STRIDE;

@@ -23,5 +23,5 @@ def run(n, m, N, cb="jacobian", steps=3):
 for cb in ("constraint","jacobian","hessian"):
     run(64, 4, 1000, cb)
 for cb in ("constraint","jacobian","hessian"):
-    run(1024, 4, 128, cb, steps=2)
+    run(1024, 4, 500, cb, steps=2)  # configs[4] per-GPU share: N=4000 over 8 GPUs
 run(4, 2, 51, "jacobian"); run(4, 2, 51, "hessian")
