@@ -22,6 +22,8 @@ from .host.problem import (  # noqa: F401
     CompositeObjective,
     KnotPointObjective,
     TerminalObjective,
+    HostIntegrator,
+    TimeDependentBilinearIntegrator,
     ket_fidelity_factor,
     NonlinearKnotPointConstraint,
     DirectTrajOptProblem,

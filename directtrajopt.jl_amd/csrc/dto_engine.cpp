@@ -139,8 +139,9 @@ struct dto_handle {
     std::vector<ConHost> con;
     std::vector<KObj> obj;
     std::vector<ExtObjHost> ext_obj;
-    std::vector<ExtSlot> ext;      // external constraints in list order, then external objectives in list order
-    int n_ext_con = 0, n_ext_obj = 0;
+    std::vector<KExtInt> ext_int;  // DTO_INTEGRATOR_EXTERNAL, slot = index
+    std::vector<ExtSlot> ext;      // external integrators, then constraints, then objectives, each in list order
+    int n_ext_int = 0, n_ext_con = 0, n_ext_obj = 0;
     std::vector<std::pair<int64_t, int64_t>> row_segments;  // (global start 0-based, len)
     int64_t cons_len = 0;
     dto_shard_info info{};
@@ -732,6 +733,8 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
         }
     }
     for (auto& d : h->der) launch_cons_derivative(st, h->P, d, dZ, dg);
+    for (size_t i = 0; i < h->ext_int.size(); ++i)
+        if (h->P.n_int > 0) launch_extint_cons(st, h->P, h->ext_int[i], ext_upload(h, (int)i, 0, st), dg);
     for (auto& c : h->con) {
         if (!c.external) launch_cons_knot(st, h->P, c.k, dZ, dg);
         else if (c.k.n_times > 0) launch_ext_cons(st, c.k, ext_upload(h, c.ext_slot, 0, st), dg);
@@ -774,6 +777,8 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
         launch_jac_bilinear(st, h->P, b.k, b.fw, dvals);
     }
     for (auto& d : h->der) launch_jac_derivative(st, h->P, d, dZ, dvals);
+    for (size_t i = 0; i < h->ext_int.size(); ++i)
+        launch_extint_jac(st, h->P, h->ext_int[i], ext_upload(h, (int)i, 1, st), dvals);
     for (auto& c : h->con) {
         if (!c.external) launch_jac_knot(st, h->P, c.k, dZ, dvals);
         else if (c.k.n_times > 0) launch_ext_jac(st, c.k, ext_upload(h, c.ext_slot, 1, st), dvals);
@@ -817,8 +822,11 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 }
                 launch_hess_pair(st, h->P, b.k, b.fw, nf, b.EP, dH);
             }
-        } else {
+        } else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) {
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
+        } else {  // the caller's blocks already carry mu_k (eval_hessian_of_lagrangian(integrator, traj, mu_slice))
+            const int e = h->integ_index[i];
+            launch_extint_hess(st, h->P, h->ext_int[e], ext_upload(h, e, 2, st), dH);
         }
     }
     for (auto& c : h->con) {
@@ -931,7 +939,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         int64_t row = 0;
         for (int i = 0; i < d->n_integrators; ++i) {
             const dto_integrator_desc& s = d->integrators[i];
-            if (s.x_dim < 1 || s.x_off < 0 || s.x_off + s.x_dim > d->z) throw HipError{"integrator: bad state range"};
+            if (s.x_dim < 1 || (s.kind != DTO_INTEGRATOR_EXTERNAL && (s.x_off < 0 || s.x_off + s.x_dim > d->z)))
+                throw HipError{"integrator: bad state range"};
             h->integ_kind.push_back(s.kind);
             h->integ_dim.push_back(s.x_dim);
             h->integ_row_off.push_back(row);
@@ -973,14 +982,26 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 k.d = s.x_dim; k.x_off = s.x_off; k.xdot_off = s.u_off; k.pre = pre; k.row_off = row;
                 h->integ_index.push_back((int)h->der.size());
                 h->der.push_back(k);
+            } else if (s.kind == DTO_INTEGRATOR_EXTERNAL) {
+                KExtInt e{};
+                e.d = s.x_dim; e.pre = pre; e.row_off = row;
+                h->integ_index.push_back((int)h->ext_int.size());
+                h->ext_int.push_back(e);
+                ExtSlot sl;
+                sl.len[0] = (size_t)s.x_dim * h->K;
+                sl.len[1] = (size_t)s.x_dim * 2 * d->z * h->K;
+                sl.len[2] = (size_t)4 * d->z * d->z * h->K;
+                h->ext.push_back(sl);
             } else {
-                throw HipError{"unknown integrator kind (TimeDependentBilinearIntegrator and user integrators stay on the host)"};
+                throw HipError{"unknown integrator kind"};
             }
             pre += s.x_dim;
             row += (int64_t)s.x_dim * h->K;
         }
         h->D = pre;
         h->n_dyn = row;
+        h->n_ext_int = (int)h->ext_int.size();
+        if (h->integ_kind.size() > 8) throw HipError{"at most 8 integrators"};
 
         // nonlinear knot constraints: rows follow the dynamics (evaluator.jl:219-223)
         for (int i = 0; i < d->n_constraints; ++i) {
@@ -1016,14 +1037,14 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         h->n_cons = row;
         for (auto& c : h->con)
             if (c.external) {
-                c.ext_slot = (int)h->ext.size();
+                c.ext_slot = (int)h->ext.size();  // after the external integrators
                 ExtSlot e;
                 e.len[0] = (size_t)c.g_dim * c.n_times_total;
                 e.len[1] = (size_t)c.g_dim * c.comps.size() * c.n_times_total;
                 e.len[2] = c.comps.size() * c.comps.size() * (size_t)c.n_times_total;
                 h->ext.push_back(e);
             }
-        h->n_ext_con = (int)h->ext.size();
+        h->n_ext_con = (int)h->ext.size() - h->n_ext_int;
 
         // shard
         KProb& P = h->P;
@@ -1056,7 +1077,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         for (size_t i = 0; i < h->integ_kind.size(); ++i) {
             const int dd = h->integ_dim[i];
             if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) h->bil[h->integ_index[i]].k.lrow_off = lrow;
-            else h->der[h->integ_index[i]].lrow_off = lrow;
+            else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) h->der[h->integ_index[i]].lrow_off = lrow;
+            else h->ext_int[h->integ_index[i]].lrow_off = lrow;
             if (P.n_int > 0) h->row_segments.emplace_back(h->integ_row_off[i] + P.kn_lo * dd, P.n_int * dd);
             lrow += P.n_int * dd;
         }
@@ -1387,16 +1409,17 @@ int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper) {
     return 0;
 }
 
-int dto_num_external(const dto_handle* h, int32_t* n_constraints, int32_t* n_objectives) {
+int dto_num_external(const dto_handle* h, int32_t* n_integrators, int32_t* n_constraints, int32_t* n_objectives) {
     if (!h) return 1;
+    if (n_integrators) *n_integrators = h->n_ext_int;
     if (n_constraints) *n_constraints = h->n_ext_con;
     if (n_objectives) *n_objectives = h->n_ext_obj;
     return 0;
 }
 int dto_set_external(dto_handle* h, int32_t n, const dto_external_values* v) {
     if (!h) return 1;
-    if (n != h->n_ext_con + h->n_ext_obj || (n > 0 && !v))
-        return fail(h, "dto_set_external: one entry per external term is required (constraints, then objectives)");
+    if (n != h->n_ext_int + h->n_ext_con + h->n_ext_obj || (n > 0 && !v))
+        return fail(h, "dto_set_external: one entry per external term is required (integrators, constraints, objectives)");
     for (int i = 0; i < n && i < (int)h->ext.size(); ++i) h->ext[i].v = v[i];
     return 0;
 }
@@ -1506,6 +1529,7 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
     bool mfree = h->eval_hessian != 0 || transpose == 0;  // the adjoint sweep buffers exist only with eval_hessian
     for (auto& b : h->bil) mfree = mfree && !b.small && (transpose == 0 || b.ad.S != nullptr) && b.k.m + 2 <= MAX_TYPES;
     for (auto& c : h->con) mfree = mfree && !c.external;  // external blocks are placed into the value slab
+    mfree = mfree && h->ext_int.empty();
     static const bool mfree_on = [] { const char* e = getenv("DTO_JV_MATRIX_FREE"); return !e || atoi(e) != 0; }();
     if (mfree && mfree_on) {
         const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;

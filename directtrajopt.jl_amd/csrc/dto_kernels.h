@@ -53,6 +53,12 @@ __host__ __device__ inline int64_t jac_pos(const KProb& P, const int64_t* colptr
 }
 
 // position of upper-triangular Hessian entry (a <= b, knot-local comps) of diagonal block kn
+// entry (row a of knot kn-1, column b of knot kn) of the off-diagonal block, kn >= 1
+__host__ __device__ inline int64_t hess_pos_off(const KProb& P, int64_t kn, int a, int b) {
+    const int64_t z = P.z;
+    const int64_t tri = z * (z + 1) / 2;
+    return tri + (kn - 1) * (z * z + tri) + (int64_t)b * z + (int64_t)b * (b + 1) / 2 + a - P.hess_lo;
+}
 __host__ __device__ inline int64_t hess_pos(const KProb& P, int64_t kn, int a, int b) {
     const int64_t z = P.z;
     const int64_t tri = z * (z + 1) / 2;
@@ -173,6 +179,15 @@ void launch_cons_knot(hipStream_t st, const KProb& P, const KCon& C, const doubl
 void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* w, double* y, int transpose);
 void launch_jac_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* vals);
 void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* dmu, double* H);
+
+// host-evaluated integrator (DTO_INTEGRATOR_EXTERNAL): placement of the caller's per-interval blocks
+struct KExtInt {
+    int32_t d, pre;        // rows per interval; rows of the integrators before it (per interval)
+    int64_t row_off, lrow_off;
+};
+void launch_extint_cons(hipStream_t st, const KProb& P, const KExtInt& E, const double* vals, double* g);
+void launch_extint_jac(hipStream_t st, const KProb& P, const KExtInt& E, const double* blocks, double* vals);
+void launch_extint_hess(hipStream_t st, const KProb& P, const KExtInt& E, const double* blocks, double* H);
 
 // host-evaluated knot terms (DTO_CONSTRAINT_EXTERNAL / DTO_OBJECTIVE_EXTERNAL_KNOT): scatter of caller-supplied blocks
 void launch_ext_cons(hipStream_t st, const KCon& C, const double* vals, double* g);

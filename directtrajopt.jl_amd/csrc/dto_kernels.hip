@@ -1527,6 +1527,61 @@ void launch_hess_knot(hipStream_t st, const KProb& P, const KCon& C, const doubl
 // host-evaluated knot terms: the caller ran the reference's own closures; the
 // engine only places the blocks.  Same placement rules as the built-in kinds above.
 // ============================================================================================
+// external integrator: defects of the owned intervals
+__global__ void k_extint_cons(KProb P, KExtInt E, const double* __restrict__ src, double* __restrict__ g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_int * E.d) return;
+    g[E.lrow_off + i] = src[P.kn_lo * E.d + i];
+}
+void launch_extint_cons(hipStream_t st, const KProb& P, const KExtInt& E, const double* vals, double* g) {
+    const int64_t n = P.n_int * E.d;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_extint_cons, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, E, vals, g);
+}
+// Jacobian entries of the owned knots' column blocks: rows of interval kn-1 take the z_{k+1} half of that interval's
+// block, rows of interval kn the z_k half of its own (blocks: [N-1] x (d x 2z) column-major)
+__global__ void k_extint_jac(KProb P, KExtInt E, const double* __restrict__ blocks, double* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)P.z * E.d;
+    if (i >= P.n_knots * per) return;
+    const int64_t kn = P.kn_lo + i / per;
+    const int j = (int)((i % per) / E.d), r = (int)(i % E.d);
+    const int64_t bs = (int64_t)E.d * 2 * P.z;
+    if (kn >= 1) vals[jac_pos(P, P.colptr, kn, j, E.pre, E.d, 0, r)] = blocks[(kn - 1) * bs + (int64_t)(P.z + j) * E.d + r];
+    if (kn < P.K) vals[jac_pos(P, P.colptr, kn, j, E.pre, E.d, 1, r)] = blocks[kn * bs + (int64_t)j * E.d + r];
+}
+void launch_extint_jac(hipStream_t st, const KProb& P, const KExtInt& E, const double* blocks, double* vals) {
+    const int64_t n = P.n_knots * P.z * E.d;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_extint_jac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, E, blocks, vals);
+}
+// Hessian blocks ([N-1] x (2z x 2z) column-major) into the owned knots' columns: diagonal block (kn,kn) gets the
+// z_k part of interval kn and the z_{k+1} part of interval kn-1, off-diagonal block (kn-1,kn) the cross part of kn-1
+__global__ void k_extint_hess(KProb P, const double* __restrict__ blocks, double* __restrict__ H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t z = P.z, per = z * z;
+    if (i >= P.n_knots * per) return;
+    const int64_t kn = P.kn_lo + i / per;
+    const int b = (int)((i % per) / z), a = (int)(i % z);
+    const int64_t bs = 4 * z * z, ld = 2 * z;
+    if (a <= b) {
+        double v = 0.0;
+        if (kn < P.K) v += blocks[kn * bs + a + ld * b];
+        if (kn >= 1) v += blocks[(kn - 1) * bs + (z + a) + ld * (z + b)];
+        if (v != 0.0) atomicAdd(&H[hess_pos(P, kn, a, b)], v);
+    }
+    if (kn >= 1) {
+        const double v = blocks[(kn - 1) * bs + a + ld * (z + b)];
+        if (v != 0.0) atomicAdd(&H[hess_pos_off(P, kn, a, b)], v);
+    }
+}
+void launch_extint_hess(hipStream_t st, const KProb& P, const KExtInt& E, const double* blocks, double* H) {
+    (void)E;
+    const int64_t n = P.n_knots * P.z * P.z;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_extint_hess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, blocks, H);
+}
+
 __global__ void k_ext_cons(KCon C, const double* __restrict__ src, double* __restrict__ g) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C.n_times * C.g_dim) return;

@@ -9,7 +9,7 @@ c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
 DTO_ABI_VERSION = 3
-INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE = 1, 2
+INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL = 1, 2, 3
 OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK = 1, 2, 3, 4, 5, 6
 CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL = 1, 2, 3
 
@@ -70,7 +70,7 @@ SYMBOLS = {
     "dto_jacobian_structure": (C.c_int, [H, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "dto_hessian_structure": (C.c_int, [H, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "dto_constraint_bounds": (C.c_int, [H, c_double_p, c_double_p]),
-    "dto_num_external": (C.c_int, [H, c_int32_p, c_int32_p]),
+    "dto_num_external": (C.c_int, [H, c_int32_p, c_int32_p, c_int32_p]),
     "dto_set_external": (C.c_int, [H, C.c_int32, C.POINTER(ExternalValues)]),
     "dto_eval_objective": (C.c_int, [H, c_double_p, c_double_p]),
     "dto_eval_gradient": (C.c_int, [H, c_double_p, c_double_p]),

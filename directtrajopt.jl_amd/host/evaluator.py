@@ -8,7 +8,7 @@ import numpy as np
 
 from . import capi
 from .capi import library_path, load_library  # noqa: F401
-from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, KnotPointObjective, LinearRegularizer,
+from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, HostIntegrator, KnotPointObjective, LinearRegularizer,
                       MinimumTimeObjective, NonlinearKnotPointConstraint, NullObjective, QuadraticRegularizer)
 
 
@@ -54,6 +54,7 @@ class Evaluator:
         self.eval_hessian = bool(eval_hessian)
         keep = []  # keep numpy buffers alive across dto_create
 
+        self._ext_int = []  # (integrator, first global row)
         integ = (capi.IntegratorDesc * max(1, len(prob.integrators)))()
         for i, it in enumerate(prob.integrators):
             if isinstance(it, BilinearIntegrator):
@@ -63,8 +64,11 @@ class Evaluator:
                 integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_BILINEAR, it.x_off, it.x_dim, it.u_off, it.u_dim, _dp(G))
             elif isinstance(it, DerivativeIntegrator):
                 integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_DERIVATIVE, it.x_off, it.x_dim, it.xdot_off, it.x_dim, None)
+            elif isinstance(it, HostIntegrator):
+                integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_EXTERNAL, 0, it.x_dim, 0, 0, None)
+                self._ext_int.append((it, sum(p.dim for p in prob.integrators[:i])))
             else:
-                raise NotImplementedError(f"{type(it).__name__} stays on the host (outside the hot-path scope)")
+                raise NotImplementedError(f"{type(it).__name__}: wrap it in HostIntegrator to have it merged")
 
         self._ext_con, self._ext_obj, self._ext_keep = [], [], None
         terms = _flatten_objective(prob.objective)
@@ -189,14 +193,24 @@ class Evaluator:
         """Evaluate the closure-based knot terms on the host (what the Julia shim does with the reference's
         ForwardDiff code) and hand the blocks to the engine: need 0 = values, 1 = + first derivatives,
         2 = + second derivatives; -1 = this callback does not read that family."""
-        if not (self._ext_con or self._ext_obj):
+        if not (self._ext_int or self._ext_con or self._ext_obj):
             return
         if Z is None:
             raise EngineError("closure-based terms need the host copy of Z (pass Z_host to the *_dev call)")
         traj = self.trajectory
         Zk = np.asarray(Z, dtype=np.float64)[:traj.dim * traj.N].reshape(traj.N, traj.dim)
-        vals = (capi.ExternalValues * (len(self._ext_con) + len(self._ext_obj)))()
+        ni = len(self._ext_int)
+        vals = (capi.ExternalValues * (ni + len(self._ext_con) + len(self._ext_obj)))()
         keep = []
+        for i, (it, row0) in enumerate(self._ext_int):  # integrators ride with the constraint-side callbacks
+            if con_need < 0:
+                continue
+            m = None if mu is None else np.asarray(mu, dtype=np.float64)[row0:row0 + it.dim]
+            for name, b in zip(("values", "first", "second"), it.external_blocks(Zk, con_need, m)):
+                if b is not None:
+                    b = np.ascontiguousarray(b, dtype=np.float64)
+                    keep.append(b)
+                    setattr(vals[i], name, _dp(b))
         row = self.n_dynamics_constraints
         rows = {}
         for c in self._nl_constraints:
@@ -211,7 +225,7 @@ class Evaluator:
                 if b is not None:
                     b = np.ascontiguousarray(b, dtype=np.float64)
                     keep.append(b)
-                    setattr(vals[i], name, _dp(b))
+                    setattr(vals[ni + i], name, _dp(b))
         for j, o in enumerate(self._ext_obj):
             if obj_need < 0:
                 continue
@@ -220,7 +234,7 @@ class Evaluator:
                 if b is not None:
                     b = np.ascontiguousarray(b, dtype=np.float64)
                     keep.append(b)
-                    setattr(vals[len(self._ext_con) + j], name, _dp(b))
+                    setattr(vals[ni + len(self._ext_con) + j], name, _dp(b))
         self._ext_keep = (vals, keep)  # the engine reads these host buffers during the next callbacks
         self._check(self._lib.dto_set_external(self._h, len(vals), vals))
 

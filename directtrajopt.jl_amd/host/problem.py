@@ -54,6 +54,79 @@ class DerivativeIntegrator:
         self.xdot_off = traj.components[xdot][0]
 
 
+class HostIntegrator:
+    """Any other AbstractIntegrator (src/integrators/_integrators.jl:22-34), evaluated on the host and merged by the
+    engine (DTO_INTEGRATOR_EXTERNAL).  ``f(zz, k) -> residual`` of the stacked knot pair ``zz = [z_k; z_{k+1}]`` for
+    interval ``k`` (0-based), the form the reference differentiates (time_dependent_bilinear_integrator.jl:181-203);
+    ``jac(zz, k) -> (x_dim, 2z)`` and ``hess(zz, k, mu) -> (2z, 2z)`` are optional (else host/closures.py)."""
+
+    external = True
+
+    def __init__(self, f, x_dim, traj, jac=None, hess=None):
+        self.f, self.jac, self.hess = f, jac, hess
+        self.x_dim = int(x_dim)
+        self.dim = self.x_dim * (traj.N - 1)
+        self.var_dim = 2 * traj.dim
+
+    def external_blocks(self, Zk, need, mu=None):
+        """values [K, d]; Jacobian blocks [K, 2z, d] (= column-major d x 2z); Hessian blocks of mu_k' f [K, 2z, 2z]."""
+        from . import closures
+        N, z = Zk.shape
+        K, d = N - 1, self.x_dim
+        vals = np.zeros((K, d))
+        first = np.zeros((K, 2 * z, d)) if need >= 1 else None
+        second = np.zeros((K, 2 * z, 2 * z)) if need >= 2 else None
+        for k in range(K):
+            zz = np.concatenate([Zk[k], Zk[k + 1]])
+            vals[k] = np.asarray(self.f(zz, k), dtype=np.float64).reshape(d)
+            if need >= 1:
+                first[k] = closures.jacobian(lambda x, p: self.f(x, k), zz, None, d,
+                                             None if self.jac is None else (lambda x, p: self.jac(x, k))).T
+            if need >= 2:
+                m = np.asarray(mu[k * d:(k + 1) * d], dtype=np.float64)
+                Hm = closures.hessian(lambda x: m @ np.asarray(self.f(x, k)).reshape(d), zz,
+                                      None if self.jac is None else (lambda x: m @ np.asarray(self.jac(x, k)).reshape(d, 2 * z)),
+                                      None if self.hess is None else (lambda x: self.hess(x, k, m)))
+                second[k] = Hm.T
+        return vals, first, second
+
+
+class TimeDependentBilinearIntegrator(HostIntegrator):
+    """TimeDependentBilinearIntegrator(G, x, u, t, traj; spline_order=1) --
+    src/integrators/time_dependent_bilinear_integrator.jl:60-140: defect x_{k+1} - Phi_k x_k for
+    dx/dtau = dt_k G(u(tau), t_k + tau dt_k) x on tau in [0, 1], controls held (order 0) or linearly interpolated to
+    u_{k+1} (order 1).  ``G(u, t)`` is an arbitrary closure, so this integrator is host-evaluated and merged.  Where the
+    reference integrates with adaptive Tsit5 (default tolerances) and differentiates through the solver, this mirror
+    uses fixed-step RK4 (``substeps`` per interval; an analytic map, so complex-step derivatives are exact for it)."""
+
+    def __init__(self, G, x, u, t, traj, spline_order=1, substeps=32):
+        if spline_order not in (0, 1):
+            raise ValueError(f"Unsupported spline order: {spline_order}")
+        self.G, self.spline_order, self.substeps = G, int(spline_order), int(substeps)
+        self.x_name, self.u_name, self.t_name = x, u, t
+        self.u_dim = traj.dims[u]
+        z = traj.dim
+        xc, uc = np.asarray(traj.components[x]), np.asarray(traj.components[u])
+        tc, dtc = traj.components[t][0], traj.components[traj.timestep][0]
+
+        def f(zz, k):
+            xk, uk, tk, dt = zz[xc], zz[uc], zz[tc], zz[dtc]
+            xk1, uk1 = zz[z + xc], zz[z + uc]
+            ctrl = (lambda tau: uk) if self.spline_order == 0 else (lambda tau: uk + tau * (uk1 - uk))
+            rhs = lambda tau, y: dt * (np.asarray(self.G(ctrl(tau), tk + tau * dt)) @ y)
+            y, h = xk, 1.0 / self.substeps
+            for i in range(self.substeps):
+                tau = i * h
+                k1 = rhs(tau, y)
+                k2 = rhs(tau + 0.5 * h, y + 0.5 * h * k1)
+                k3 = rhs(tau + 0.5 * h, y + 0.5 * h * k2)
+                k4 = rhs(tau + h, y + h * k3)
+                y = y + (h / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+            return xk1 - y
+
+        super().__init__(f, traj.dims[x], traj)
+
+
 class AbstractObjective:
     def __add__(self, other):
         """`+` flattens nested composites -- src/objectives/_objectives.jl:165-176."""

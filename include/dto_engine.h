@@ -36,6 +36,11 @@ extern "C" {
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
 #define DTO_INTEGRATOR_DERIVATIVE 2 /* derivative_integrator.jl:26-49 */
+#define DTO_INTEGRATOR_EXTERNAL 3   /* any other AbstractIntegrator (TimeDependentBilinearIntegrator,
+                                       time_dependent_bilinear_integrator.jl:60-244; user integrators): evaluated
+                                       on the HOST by the reference's own code, merged by the engine.  Structure is
+                                       the generic one (dense x_dim x 2z block per interval, _integrators.jl:49-77);
+                                       only x_dim is read from the descriptor */
 
 /* objective term kinds (src/objectives/) */
 #define DTO_OBJECTIVE_QUADRATIC_REGULARIZER 1 /* regularizers.jl:38-167   */
@@ -164,11 +169,14 @@ int dto_hessian_structure(const dto_handle* h, int64_t first, int64_t count, int
 /* row bounds handed to the solver, src/solvers/solve.jl:30-65: lower/upper per NLP row */
 int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper);
 
-/* Host-evaluated ("external") knot-point terms -- SURVEY.md §8f rank 2.  One entry per EXTERNAL term: the
- * external constraints in list order, then the external objectives in list order.  All pointers are HOST
+/* Host-evaluated ("external") terms -- SURVEY.md §8f rank 2.  One entry per EXTERNAL term: the external
+ * integrators in list order, then the external constraints in list order, then the external objectives.  All pointers are HOST
  * pointers; they are read (copied to the device) by every callback that follows until replaced, so the shim
  * fills whatever the next callback needs and calls dto_set_external first.  Arrays cover ALL listed times of the
  * term, in list order; a sharded handle reads only the blocks of its own knots.
+ *   integrator: values = defects, [N-1] x x_dim;  first = Jacobian blocks, [N-1] x (x_dim x 2z col-major, columns
+ *               z_k then z_{k+1});  second = Hessian blocks of mu_k' f, [N-1] x (2z x 2z col-major) -- accumulated (+=)
+ *               like every integrator block (evaluator.jl:574-598), row <= col entries only
  *   constraint: values = g, [n_times] x g_dim;  first = Jacobian blocks, [n_times] x (g_dim x n_comps col-major);
  *               second = Hessian blocks of mu_i' g, [n_times] x (n_comps x n_comps col-major)
  *   objective:  values = Q_i l(v_i, p_i), [n_times];  first = Q_i grad l, [n_times] x n_comps;
@@ -181,7 +189,7 @@ typedef struct dto_external_values {
     const double* first;
     const double* second;
 } dto_external_values;
-int dto_num_external(const dto_handle* h, int32_t* n_constraints, int32_t* n_objectives);
+int dto_num_external(const dto_handle* h, int32_t* n_integrators, int32_t* n_constraints, int32_t* n_objectives);
 int dto_set_external(dto_handle* h, int32_t n, const dto_external_values* v);
 
 /* host-pointer callbacks (blocking) */

@@ -59,6 +59,21 @@ class DerivativeIntegrator:
 
 
 @dataclass
+class ClosureIntegrator:
+    """Any other AbstractIntegrator (src/integrators/_integrators.jl:22-34), e.g. TimeDependentBilinearIntegrator
+    (time_dependent_bilinear_integrator.jl:60-244): residual f(zz, k) of the stacked knot pair zz = [z_k; z_{k+1}]
+    with analytic jac(zz, k) -> (x_dim, 2z) and hess(zz, k, mu) -> (2z, 2z) standing in for ForwardDiff
+    (:178-244).  Structure: the generic dense block per interval (_integrators.jl:49-77)."""
+
+    f: object
+    jac: object
+    hess: object
+    x_dim: int
+
+    kind = "external"
+
+
+@dataclass
 class QuadraticRegularizer:
     """src/objectives/regularizers.jl:38-167."""
 
@@ -237,6 +252,9 @@ def integrator_evaluate(integ, prob, Z):
     out = np.zeros(d * prob.K)
     for k in range(prob.K):
         zk, zk1 = _knot(Z, prob, k), _knot(Z, prob, k + 1)
+        if integ.kind == "external":
+            out[k * d:(k + 1) * d] = np.asarray(integ.f(np.concatenate([zk, zk1]), k), dtype=np.float64)
+            continue
         dt = zk[prob.dt_idx]
         xk = zk[integ.x_off:integ.x_off + d]
         xk1 = zk1[integ.x_off:integ.x_off + d]
@@ -289,6 +307,10 @@ def integrator_jacobian(integ, prob, Z):
     for k in range(prob.K):
         zk = _knot(Z, prob, k)
         blk = np.zeros((d, 2 * z))
+        if integ.kind == "external":
+            zz = np.concatenate([zk, _knot(Z, prob, k + 1)])
+            J[k * d:(k + 1) * d, k * z:(k + 2) * z] = np.asarray(integ.jac(zz, k), dtype=np.float64).reshape(d, 2 * z)
+            continue
         if integ.kind == "bilinear":
             blk[:, :z] = bilinear_block_jacobian(integ, prob, zk)
         else:
@@ -371,7 +393,10 @@ def integrator_hessian(integ, prob, Z, mu):
         zk = _knot(Z, prob, k)
         muk = mu[k * d:(k + 1) * d]
         blk = np.zeros((2 * z, 2 * z))
-        if integ.kind == "bilinear":
+        if integ.kind == "external":
+            zz = np.concatenate([zk, _knot(Z, prob, k + 1)])
+            blk = np.asarray(integ.hess(zz, k, muk), dtype=np.float64).reshape(2 * z, 2 * z)
+        elif integ.kind == "bilinear":
             blk[:z, :z] = bilinear_block_hessian(integ, prob, zk, muk)
         else:
             for i in range(d):
@@ -860,6 +885,53 @@ def make_standard_problem(N=10, seed=3, omega=0.1):
         weights=[1.0, 1.0, 1.0, 1.0],
         constraints=[KnotConstraint("norm", [4, 5], 1.0, list(range(2, N)), equality=False)],
         Z0=data.T.reshape(-1).copy())
+
+
+def make_external_integrator_problem(N=7, seed=9):
+    """Standard problem with one MORE integrator evaluated outside the engine, placed between the built-in ones: a
+    nonlinear two-row defect that also reads z_{k+1} components other than the state (u_{k+1}) and the interval index,
+        f_r = y_{k+1,r} - y_{k,r} - dt_k ( sin(y_{k,r}) u_{k,0} + w_k y_{k+1,r} u_{k+1,1} ),   y = ddu (comps 8, 9),
+    so both halves of the Jacobian block and all three parts of the 2z x 2z Hessian block (diagonal z_k, diagonal
+    z_{k+1}, cross) are non-trivial.  The shape a TimeDependentBilinearIntegrator has (:178-244)."""
+    prob = make_standard_problem(N=N, seed=seed)
+    z, y0, u0, dti = prob.z, 8, 4, prob.dt_idx
+    w = 0.1 + 0.05 * np.arange(N)
+
+    def f(zz, k):
+        yk, yk1, dt = zz[y0:y0 + 2], zz[z + y0:z + y0 + 2], zz[dti]
+        return yk1 - yk - dt * (np.sin(yk) * zz[u0] + w[k] * yk1 * zz[z + u0 + 1])
+
+    def jac(zz, k):
+        yk, yk1, dt = zz[y0:y0 + 2], zz[z + y0:z + y0 + 2], zz[dti]
+        J = np.zeros((2, 2 * z))
+        for r in range(2):
+            J[r, y0 + r] = -1.0 - dt * np.cos(yk[r]) * zz[u0]
+            J[r, u0] = -dt * np.sin(yk[r])
+            J[r, dti] = -(np.sin(yk[r]) * zz[u0] + w[k] * yk1[r] * zz[z + u0 + 1])
+            J[r, z + y0 + r] = 1.0 - dt * w[k] * zz[z + u0 + 1]
+            J[r, z + u0 + 1] = -dt * w[k] * yk1[r]
+        return J
+
+    def hess(zz, k, mu):
+        yk, yk1, dt = zz[y0:y0 + 2], zz[z + y0:z + y0 + 2], zz[dti]
+        H = np.zeros((2 * z, 2 * z))
+
+        def sym(a, b, v):
+            H[a, b] += v
+            if a != b:
+                H[b, a] += v
+        for r in range(2):
+            sym(y0 + r, y0 + r, mu[r] * dt * np.sin(yk[r]) * zz[u0])
+            sym(y0 + r, u0, -mu[r] * dt * np.cos(yk[r]))
+            sym(y0 + r, dti, -mu[r] * np.cos(yk[r]) * zz[u0])
+            sym(u0, dti, -mu[r] * np.sin(yk[r]))
+            sym(dti, z + y0 + r, -mu[r] * w[k] * zz[z + u0 + 1])
+            sym(dti, z + u0 + 1, -mu[r] * w[k] * yk1[r])
+            sym(z + y0 + r, z + u0 + 1, -mu[r] * dt * w[k])
+        return H
+
+    prob.integrators = [prob.integrators[0], ClosureIntegrator(f, jac, hess, 2)] + prob.integrators[1:]
+    return prob
 
 
 def ket_fidelity_factor(goal_iso):

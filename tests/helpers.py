@@ -12,6 +12,8 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
     # one trajectory component per distinct range mentioned by the problem; leftovers become filler
     ranges = {}
     for it in prob.integrators:
+        if it.kind == "external":
+            continue
         ranges[(it.x_off, it.x_dim)] = None
         if it.kind == "bilinear":
             if it.u_dim:
@@ -38,6 +40,11 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
     assert traj.dim == z
     integ = []
     for it in prob.integrators:
+        if it.kind == "external":
+            analytic = closure_derivatives == "analytic"
+            integ.append(dto_amd.HostIntegrator(it.f, it.x_dim, traj, jac=it.jac if analytic else None,
+                                                hess=it.hess if analytic else None))
+            continue
         if it.kind == "bilinear":
             if it.u_dim == 0:
                 raise NotImplementedError

@@ -98,6 +98,7 @@ PROBLEMS = {
     "scaled_con": lambda: O.make_scaled_problem(7, 5, 3, seed=8, with_constraint=True),
     "closure": lambda: O.make_closure_problem(),
     "ket": lambda: O.make_ket_problem(),
+    "external_integrator": lambda: O.make_external_integrator_problem(),
 }
 
 
@@ -199,9 +200,12 @@ def test_external_terms_are_counted_and_required():
     """dto_num_external / dto_set_external on a structure-only handle (no GPU): slot count and argument check."""
     p = O.make_closure_problem()
     ev = dto_amd.Evaluator(to_engine(p), device=-1)
-    nc, no = ctypes.c_int32(), ctypes.c_int32()
-    assert ev._lib.dto_num_external(ev.handle, ctypes.byref(nc), ctypes.byref(no)) == 0
-    assert (nc.value, no.value) == (1, 1)
+    ni, nc, no = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert ev._lib.dto_num_external(ev.handle, ctypes.byref(ni), ctypes.byref(nc), ctypes.byref(no)) == 0
+    assert (ni.value, nc.value, no.value) == (0, 1, 1)
+    ev2 = dto_amd.Evaluator(to_engine(O.make_external_integrator_problem()), device=-1)
+    assert ev2._lib.dto_num_external(ev2.handle, ctypes.byref(ni), ctypes.byref(nc), ctypes.byref(no)) == 0
+    assert (ni.value, nc.value, no.value) == (1, 0, 0)
     assert ev._lib.dto_set_external(ev.handle, 1, None) != 0  # needs exactly 2 entries
     vals = (dto_amd.capi.ExternalValues * 2)()
     assert ev._lib.dto_set_external(ev.handle, 2, vals) == 0

@@ -168,3 +168,72 @@ def test_large_state_shapes_against_the_oracle(n, m, N):
     knots so that the oracle (scipy expm/expm_frechet, block-triangular second-order terms) finishes in seconds:
     128 and 256 take the generator-subspace powers, 192 (not a multiple of 128) the plain GEMM chain."""
     _check(O.make_scaled_problem(N, n, m, seed=11), tag=f"large-state n={n}")
+
+
+def test_external_integrator_merged_from_host_blocks():
+    """an integrator evaluated outside the engine (the shape TimeDependentBilinearIntegrator has:
+    both knot halves of the Jacobian block, cross part of the Hessian block) placed between built-in integrators."""
+    p = O.make_external_integrator_problem()
+    _check(p, tag="extint/analytic", closure_derivatives="analytic")
+    Z = p.Z0 + 0.05 * np.random.default_rng(4).standard_normal(p.n_vars)
+    _check(p, Z=Z, tag="extint/numeric", closure_derivatives="numeric", tol_h=1e-6)
+
+
+def test_external_integrator_sharded():
+    import dto_amd
+    p = O.make_external_integrator_problem(N=9)
+    ev_o = O.OracleEvaluator(p)
+    Z = p.Z0 + 0.02 * np.random.default_rng(5).standard_normal(p.n_vars)
+    mu = np.random.default_rng(6).standard_normal(ev_o.n_constraints)
+    ref = {"jac": ev_o.eval_constraint_jacobian(Z), "hess": ev_o.eval_hessian_lagrangian(Z, 0.3, mu), "cons": ev_o.eval_constraint(Z)}
+    got = {k: np.full_like(v, np.nan) for k, v in ref.items()}
+    for lo, hi in dto_amd.distributed.shard_ranges(p.N, 4):
+        ev = dto_amd.Evaluator(to_engine(p, "analytic"), k_lo=lo, k_hi=hi)
+        s = ev.shard
+        o = np.empty(s.jac_len); ev.eval_constraint_jacobian(o, Z); got["jac"][s.jac_lo:s.jac_lo + s.jac_len] = o
+        o = np.empty(s.hess_len); ev.eval_hessian_lagrangian(o, Z, 0.3, mu); got["hess"][s.hess_lo:s.hess_lo + s.hess_len] = o
+        o = np.empty(s.cons_len); ev.eval_constraint(o, Z)
+        st, ln = ev.shard_rows()
+        pos = 0
+        for a, b in zip(st, ln):
+            got["cons"][a - 1:a - 1 + b] = o[pos:pos + b]
+            pos += b
+        ev.close()
+    for k in ref:
+        assert rel_err(got[k], ref[k]) <= (1e-8 if k == "hess" else 1e-10), k
+
+
+def test_time_dependent_bilinear_through_the_merge_path():
+    """TimeDependentBilinearIntegrator (host mirror: fixed-step RK4) in a full problem: the engine's merged Jacobian
+    must equal finite differences of its merged constraint values, and with a time-independent G and zero-order hold
+    the rows must coincide with a device BilinearIntegrator on the same data."""
+    import dto_amd
+    rng = np.random.default_rng(3)
+    N = 6
+    traj = dto_amd.NamedTrajectory({"x": rng.standard_normal((2, N)), "u": 0.3 * rng.standard_normal((1, N)),
+                                    "t": np.linspace(0.0, 1.0, N)[None, :], "dt": np.full((1, N), 0.2)}, timestep="dt")
+    G0, G1 = np.array([[-0.1, 1.0], [-1.0, -0.1]]), np.array([[0.0, 1.0], [1.0, 0.0]])
+    tdb = dto_amd.TimeDependentBilinearIntegrator(lambda u, t: G0 + u[0] * G1, "x", "u", "t", traj, spline_order=0, substeps=64)
+    bil = dto_amd.BilinearIntegrator(np.stack([G0, G1]), "x", "u", traj)
+    prob = dto_amd.DirectTrajOptProblem(traj, dto_amd.QuadraticRegularizer("u", traj, 1.0), [tdb, bil])
+    ev = dto_amd.Evaluator(prob)
+    try:
+        Z = traj.vec()
+        g = np.empty(ev.n_constraints); ev.eval_constraint(g, Z)
+        d = 2 * (N - 1)
+        assert np.allclose(g[:d], g[d:], atol=1e-9)
+        J = np.empty(ev.n_jacobian_entries); ev.eval_constraint_jacobian(J, Z)
+        r, c = ev.jacobian_structure()
+        M = np.zeros((ev.n_constraints, ev.n_variables)); M[r - 1, c - 1] = J
+        assert np.allclose(M[:d], M[d:], atol=1e-7)
+        eps = 1e-6
+        for col in (0, 2, 3, 5, 8):
+            e = np.zeros_like(Z); e[col] = eps
+            gp = np.empty_like(g); gm = np.empty_like(g)
+            ev.eval_constraint(gp, Z + e); ev.eval_constraint(gm, Z - e)
+            assert np.allclose((gp - gm) / (2 * eps), M[:, col], atol=1e-6)
+        mu = rng.standard_normal(ev.n_constraints)
+        H = np.empty(ev.n_hessian_entries); ev.eval_hessian_lagrangian(H, Z, 1.0, mu)
+        assert np.isfinite(H).all()
+    finally:
+        ev.close()

@@ -249,3 +249,55 @@ def test_ket_infidelity_loss_is_the_fidelity():
     dup = [(3 - 1) * p.z + c for c in range(4)]  # knot 3 is listed twice: last listing only (knot_point_objectives.jl:198)
     keep = np.setdiff1d(np.arange(nv), dup)
     assert np.allclose(gfd[keep], gr[keep], atol=1e-7)
+
+
+def test_external_integrator_passes_the_reference_fd_bars():
+    """The closure integrator of the oracle (shape of TimeDependentBilinearIntegrator's blocks: both knot halves, cross
+    Hessian part) against finite differences at the reference's tolerances (_integrators.jl:97-242: 1e-3/1e-5)."""
+    p = O.make_external_integrator_problem(N=5)
+    ev = O.OracleEvaluator(p)
+    Z = p.Z0.copy()
+    nv, eps = p.n_vars, 1e-6
+    rows, cols = ev.jacobian_structure1()
+    J = np.zeros((ev.n_constraints, nv))
+    J[rows - 1, cols - 1] = ev.eval_constraint_jacobian(Z)
+    Jfd = np.stack([(ev.eval_constraint(Z + eps * e) - ev.eval_constraint(Z - eps * e)) / (2 * eps) for e in np.eye(nv)], axis=1)
+    assert np.allclose(J, Jfd, atol=1e-6, rtol=1e-6)
+    mu = np.random.default_rng(0).standard_normal(ev.n_constraints)
+
+    def gradL(zv):
+        M = np.zeros((ev.n_constraints, nv))
+        M[rows - 1, cols - 1] = ev.eval_constraint_jacobian(zv)
+        return ev.eval_objective_gradient(zv) + M.T @ mu
+
+    hr, hc = ev.hessian_structure1()
+    Hu = np.zeros((nv, nv))
+    Hu[hr - 1, hc - 1] = ev.eval_hessian_lagrangian(Z, 1.0, mu)
+    Hs = Hu + np.triu(Hu, 1).T
+    Hfd = np.stack([(gradL(Z + eps * e) - gradL(Z - eps * e)) / (2 * eps) for e in np.eye(nv)], axis=1)
+    assert np.allclose(Hs, Hfd, atol=1e-5)
+    assert np.abs(Hs[:p.z, p.z:2 * p.z]).max() > 1e-3  # the cross (z_k, z_{k+1}) part is really exercised
+
+
+def test_time_dependent_bilinear_mirror_reduces_to_the_exponential():
+    """Host mirror of TimeDependentBilinearIntegrator: with a time-independent G and zero-order hold its defect is the
+    BilinearIntegrator's (x_{k+1} - exp(dt G(u)) x_k) up to the RK4 step error, and with the carrier example of the
+    reference's docstring (time_dependent_bilinear_integrator.jl:52-55) it matches a fine-step reference solve."""
+    import dto_amd
+    import scipy.linalg as sla
+    rng = np.random.default_rng(1)
+    N = 4
+    traj = dto_amd.NamedTrajectory({"x": rng.standard_normal((2, N)), "u": 0.3 * rng.standard_normal((1, N)),
+                                    "t": np.linspace(0.0, 0.6, N)[None, :], "dt": np.full((1, N), 0.2)}, timestep="dt")
+    G0, G1 = np.array([[-0.1, 1.0], [-1.0, -0.1]]), np.array([[0.0, 1.0], [1.0, 0.0]])
+    Zk = traj.vec().reshape(N, traj.dim)
+    B = dto_amd.TimeDependentBilinearIntegrator(lambda u, t: G0 + u[0] * G1, "x", "u", "t", traj, spline_order=0, substeps=64)
+    vals, jac, _ = B.external_blocks(Zk, 1)
+    for k in range(N - 1):
+        want = Zk[k + 1, 0:2] - sla.expm(0.2 * (G0 + Zk[k, 2] * G1)) @ Zk[k, 0:2]
+        assert np.allclose(vals[k], want, atol=1e-10)
+        assert np.allclose(jac[k].T[:, 0:2], -sla.expm(0.2 * (G0 + Zk[k, 2] * G1)), atol=1e-9)  # d/dx_k = -E
+    Gt = lambda u, t: G0 + u[0] * np.array([[0.0, np.cos(t)], [np.cos(t), 0.0]])
+    B1 = dto_amd.TimeDependentBilinearIntegrator(Gt, "x", "u", "t", traj, spline_order=1, substeps=16)
+    B2 = dto_amd.TimeDependentBilinearIntegrator(Gt, "x", "u", "t", traj, spline_order=1, substeps=256)
+    assert np.allclose(B1.external_blocks(Zk, 0)[0], B2.external_blocks(Zk, 0)[0], atol=1e-7)
