@@ -22,6 +22,9 @@ from .host.problem import (  # noqa: F401
     CompositeObjective,
     KnotPointObjective,
     TerminalObjective,
+    GlobalObjective,
+    GlobalKnotPointObjective,
+    NonlinearGlobalConstraint,
     HostIntegrator,
     TimeDependentBilinearIntegrator,
     ket_fidelity_factor,

@@ -86,20 +86,21 @@ struct ConHost {
     std::vector<int64_t> times0;  // all times (0-based knots), reference order
     std::vector<int32_t> comps;
     int g_dim = 1;
-    bool external = false;        // DTO_CONSTRAINT_EXTERNAL: values/Jacobian/Hessian blocks come from dto_set_external
+    bool external = false;        // DTO_CONSTRAINT_EXTERNAL[_GLOBAL]: values/Jacobian/Hessian blocks come from dto_set_external
+    bool global = false;          // ..._GLOBAL: `comps` index global_data; the single listing sits at the pseudo-knot N
     int ext_slot = -1;
     std::vector<double> jac0;     // external: Jacobian blocks at Z0 (pattern)
+    std::vector<double> hess0;    // global: Hessian of sum(g) at Z0 (pattern)
+    KExtTerm xk{};                // external: placement of the Hessian blocks
 };
 
-// DTO_OBJECTIVE_EXTERNAL_KNOT: placement data of a host-evaluated KnotPointObjective
+// DTO_OBJECTIVE_EXTERNAL_KNOT / _GLOBAL: placement data of a host-evaluated objective term
 struct ExtObjHost {
-    int n_comps = 0;
     double weight = 1.0;
-    int64_t n_times = 0, n_times_total = 0;  // owned / listed
-    int32_t* comps = nullptr;
-    int64_t* times = nullptr;  // owned 0-based knots
-    int64_t* tidx = nullptr;   // their index in the listed times
-    int32_t* last = nullptr;   // 0 where a later listed time names the same knot
+    bool global = false;
+    std::vector<int32_t> comps, gcomps;
+    std::vector<int64_t> times0;  // listed knots, 0-based; {N} for a GlobalObjective (no knot part)
+    KExtTerm k{};
     int ext_slot = -1;
 };
 
@@ -142,6 +143,8 @@ struct dto_handle {
     std::vector<KExtInt> ext_int;  // DTO_INTEGRATOR_EXTERNAL, slot = index
     std::vector<ExtSlot> ext;      // external integrators, then constraints, then objectives, each in list order
     int n_ext_int = 0, n_ext_con = 0, n_ext_obj = 0;
+    std::vector<int64_t> tail_colptr, tail_rows;  // Hessian entries in global-variable columns (CSC tail)
+    int64_t hess_block_nnz = 0;
     std::vector<std::pair<int64_t, int64_t>> row_segments;  // (global start 0-based, len)
     int64_t cons_len = 0;
     dto_shard_info info{};
@@ -235,7 +238,7 @@ enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BG
 // ------------------------------------------------------------------------------------------
 
 // number of integrator rows touching a column of knot kn (0-based): D per adjacent interval
-inline int col_cnt(const dto_handle* h, int64_t kn) { return (kn >= 1 ? 1 : 0) + (kn < h->K ? 1 : 0); }
+inline int col_cnt(const dto_handle* h, int64_t kn) { return kn >= h->N ? 0 : (kn >= 1 ? 1 : 0) + (kn < h->K ? 1 : 0); }
 
 double con_jac_value(const ConHost& c, const double* zk, int comp_i) {
     double s = 0.0;
@@ -282,10 +285,41 @@ void build_structure(dto_handle* h, const double* Z0) {
             h->colptr[c + 1] = h->colptr[c] + per + extra[c];
         }
     }
-    for (int64_t c = h->N * h->z; c < nv; ++c) h->colptr[c + 1] = h->colptr[c];  // global columns: no entries
+    for (int64_t c = h->N * h->z; c < nv; ++c) h->colptr[c + 1] = h->colptr[c] + extra[c];  // global columns: only NonlinearGlobalConstraint rows
     h->jac_nnz = h->colptr[nv];
     const int64_t z = h->z;
-    h->hess_nnz = h->N * (z * (z + 1) / 2) + h->K * z * z;  // evaluator.jl:201-202 on the block pattern
+    h->hess_block_nnz = h->N * (z * (z + 1) / 2) + h->K * z * z;  // evaluator.jl:201-202 on the block pattern
+    // tail: entries whose column is a global variable (global columns follow every knot column in the CSC order).
+    // GlobalObjective / GlobalKnotPointObjective mark their whole index block (global_objectives.jl:89-101, 277-300),
+    // NonlinearGlobalConstraint contributes the non-zeros of its Hessian at mu = ones (evaluator.jl:166)
+    std::vector<std::vector<int64_t>> rows(h->gd);
+    const int64_t g0 = h->N * z;
+    for (auto& e : h->ext_obj) {
+        if (!e.global) continue;
+        for (int gb : e.gcomps) {
+            for (int64_t t : e.times0)
+                if (t < h->N)
+                    for (int ca : e.comps) rows[gb].push_back(t * z + ca);
+            for (int ga : e.gcomps)
+                if (ga <= gb) rows[gb].push_back(g0 + ga);
+        }
+    }
+    for (auto& c : h->con) {
+        if (!c.global) continue;
+        const size_t ng = c.comps.size();
+        for (size_t b = 0; b < ng; ++b)
+            for (size_t a = 0; a < ng; ++a)
+                if (c.comps[a] <= c.comps[b] && c.hess0[a + ng * b] != 0.0) rows[c.comps[b]].push_back(g0 + c.comps[a]);
+    }
+    h->tail_colptr.assign(h->gd + 1, 0);
+    h->tail_rows.clear();
+    for (int j = 0; j < h->gd; ++j) {
+        std::sort(rows[j].begin(), rows[j].end());
+        rows[j].erase(std::unique(rows[j].begin(), rows[j].end()), rows[j].end());
+        h->tail_rows.insert(h->tail_rows.end(), rows[j].begin(), rows[j].end());
+        h->tail_colptr[j + 1] = (int64_t)h->tail_rows.size();
+    }
+    h->hess_nnz = h->hess_block_nnz + (int64_t)h->tail_rows.size();
 }
 
 // first constraint-pattern entry of column c
@@ -708,15 +742,14 @@ void do_objective(dto_handle* h, const double* dZ, double* df, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(df, 0, sizeof(double), st));
     for (auto& o : h->obj) launch_objective(st, h->P, o, dZ, h->d_partial, df);
     for (auto& e : h->ext_obj)
-        if (e.n_times > 0) launch_ext_objective(st, e.tidx, e.n_times, e.weight, ext_upload(h, e.ext_slot, 0, st), df);
+        if (e.k.n_list > 0) launch_ext_objective(st, e.k, e.weight, ext_upload(h, e.ext_slot, 0, st), df);
 }
 
 void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(dgrad, 0, sizeof(double) * (size_t)h->info.grad_len, st));
     for (auto& o : h->obj) launch_gradient(st, h->P, o, dZ, dgrad);
     for (auto& e : h->ext_obj)
-        if (e.n_times > 0)
-            launch_ext_gradient(st, h->P, e.n_comps, e.comps, e.times, e.tidx, e.last, e.n_times, e.weight, ext_upload(h, e.ext_slot, 1, st), dgrad);
+        if (e.k.n_list > 0) launch_ext_gradient(st, h->P, e.k, e.weight, ext_upload(h, e.ext_slot, 1, st), dgrad);
 }
 
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
@@ -832,15 +865,12 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
     for (auto& c : h->con) {
         if (!c.external) launch_hess_knot(st, h->P, c.k, dZ, dmu, dH);
         else if (c.k.n_times > 0)  // the caller's blocks already carry mu_i (knot_point_constraint.jl:283-291)
-            launch_ext_hess(st, h->P, c.k.n_comps, c.k.comps, c.k.times, c.k.tidx, c.k.hess_on, c.k.n_times, 1.0,
-                            ext_upload(h, c.ext_slot, 2, st), dH);
+            launch_ext_hess(st, h->P, c.xk, 1.0, ext_upload(h, c.ext_slot, 2, st), dH);
     }
     if (sigma != 0.0) {
         for (auto& o : h->obj) launch_hess_objective(st, h->P, o, dZ, sigma, dH);
         for (auto& e : h->ext_obj)
-            if (e.n_times > 0)
-                launch_ext_hess(st, h->P, e.n_comps, e.comps, e.times, e.tidx, e.last, e.n_times, sigma * e.weight,
-                                ext_upload(h, e.ext_slot, 2, st), dH);
+            if (e.k.n_list > 0) launch_ext_hess(st, h->P, e.k, sigma * e.weight, ext_upload(h, e.ext_slot, 2, st), dH);
     }
 }
 
@@ -1006,8 +1036,29 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         // nonlinear knot constraints: rows follow the dynamics (evaluator.jl:219-223)
         for (int i = 0; i < d->n_constraints; ++i) {
             const dto_constraint_desc& s = d->constraints[i];
-            if (s.kind != DTO_CONSTRAINT_NORM_MINUS_C && s.kind != DTO_CONSTRAINT_SQNORM_MINUS_C && s.kind != DTO_CONSTRAINT_EXTERNAL)
+            if (s.kind != DTO_CONSTRAINT_NORM_MINUS_C && s.kind != DTO_CONSTRAINT_SQNORM_MINUS_C && s.kind != DTO_CONSTRAINT_EXTERNAL &&
+                s.kind != DTO_CONSTRAINT_EXTERNAL_GLOBAL)
                 throw HipError{"unknown constraint kind"};
+            if (s.kind == DTO_CONSTRAINT_EXTERNAL_GLOBAL) {
+                // NonlinearGlobalConstraint: one listing at the pseudo-knot N whose "components" are global_data entries
+                if (s.n_comps < 1 || !s.comps || s.g_dim < 1 || !s.jac0 || !s.hess0)
+                    throw HipError{"global constraint: comps, g_dim, jac0 and hess0 are required"};
+                ConHost c;
+                c.k.kind = s.kind; c.k.n_comps = s.n_comps; c.equality = s.equality;
+                c.external = true; c.global = true; c.g_dim = s.g_dim;
+                c.k.g_dim = c.g_dim; c.k.external = 1;
+                c.comps.assign(s.comps, s.comps + s.n_comps);
+                for (int q : c.comps)
+                    if (q < 0 || q >= d->gd) throw HipError{"global constraint: global component out of range"};
+                c.jac0.assign(s.jac0, s.jac0 + (size_t)s.g_dim * s.n_comps);
+                c.hess0.assign(s.hess0, s.hess0 + (size_t)s.n_comps * s.n_comps);
+                c.n_times_total = 1;
+                c.times0.push_back(d->N);
+                c.row_off = row;
+                row += c.g_dim;
+                h->con.push_back(std::move(c));
+                continue;
+            }
             if (s.n_comps < 1 || !s.comps || (!s.times && s.n_times > 0)) throw HipError{"constraint: bad description"};
             ConHost c;
             c.k.kind = s.kind; c.k.n_comps = s.n_comps; c.k.c = s.c;
@@ -1045,6 +1096,44 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 h->ext.push_back(e);
             }
         h->n_ext_con = (int)h->ext.size() - h->n_ext_int;
+        // host-evaluated objective terms: their slots follow, and the Global* ones shape the Hessian structure
+        for (int i = 0; i < d->n_objectives; ++i) {
+            const dto_objective_desc& s = d->objectives[i];
+            if (s.kind != DTO_OBJECTIVE_EXTERNAL_KNOT && s.kind != DTO_OBJECTIVE_EXTERNAL_GLOBAL) continue;
+            ExtObjHost e;
+            e.weight = s.weight;
+            e.global = s.kind == DTO_OBJECTIVE_EXTERNAL_GLOBAL;
+            if (s.n_comps > 0) {
+                if (!s.comps) throw HipError{"external objective: comps is null"};
+                e.comps.assign(s.comps, s.comps + s.n_comps);
+            }
+            for (int q : e.comps)
+                if (q < 0 || q >= d->z) throw HipError{"external objective: component out of range"};
+            if (e.global) {
+                if (s.n_gcomps < 1 || !s.gcomps) throw HipError{"global objective: gcomps are required"};
+                e.gcomps.assign(s.gcomps, s.gcomps + s.n_gcomps);
+                for (int q : e.gcomps)
+                    if (q < 0 || q >= d->gd) throw HipError{"global objective: global component out of range"};
+            } else if (e.comps.empty() || !s.times) {
+                throw HipError{"external knot objective: comps and times are required"};
+            }
+            if (s.n_times > 0 && !s.times) throw HipError{"external objective: times is null"};
+            for (int64_t t = 0; t < s.n_times; ++t) {
+                if (s.times[t] < 1 || s.times[t] > d->N) throw HipError{"objective: time out of range"};
+                e.times0.push_back(s.times[t] - 1);
+            }
+            if (e.times0.empty()) {  // GlobalObjective: the global variables alone
+                if (!e.comps.empty()) throw HipError{"global objective: knot components without times"};
+                e.times0.push_back(d->N);
+            }
+            const size_t nb = e.comps.size() + e.gcomps.size(), nl = e.times0.size();
+            e.ext_slot = (int)h->ext.size();
+            ExtSlot sl;
+            sl.len[0] = nl; sl.len[1] = nb * nl; sl.len[2] = nb * nb * nl;
+            h->ext.push_back(sl);
+            h->ext_obj.push_back(std::move(e));
+        }
+        h->n_ext_obj = (int)h->ext_obj.size();
 
         // shard
         KProb& P = h->P;
@@ -1068,9 +1157,14 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         I.grad_lo = c_lo;
         I.grad_len = c_hi - c_lo + (h->k_hi == h->N ? h->gd : 0);
         I.jac_lo = P.jac_lo;
-        I.jac_len = h->colptr[c_hi] - P.jac_lo;
+        I.jac_len = h->colptr[h->k_hi == h->N ? h->n_vars : c_hi] - P.jac_lo;  // global columns ride with the last knot
         I.hess_lo = P.hess_lo;
-        I.hess_len = hess_block_start(h, P.kn_lo + P.n_knots) - P.hess_lo;
+        I.hess_len = hess_block_start(h, P.kn_lo + P.n_knots) - P.hess_lo + (h->k_hi == h->N ? (int64_t)h->tail_rows.size() : 0);
+        P.tail_lo = h->k_hi == h->N ? h->hess_block_nnz - P.hess_lo : -1;
+        if (!sonly) {
+            P.tail_colptr = own(h, dupload(h->tail_colptr));
+            P.tail_rows = own(h, dupload(h->tail_rows));
+        }
 
         // local constraint rows: integrators first, then constraints
         int64_t lrow = 0;
@@ -1087,7 +1181,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             std::vector<int32_t> hess_on;
             for (int64_t i = 0; i < c.n_times_total; ++i) {
                 const int64_t kn = c.times0[i];
-                if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
+                if (kn >= h->N ? h->k_hi != h->N : (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots)) continue;  // pseudo-knot N: last rank
                 if (!h->row_segments.empty() && !times.empty() && tidx.back() == i - 1 &&
                     h->row_segments.back().first + h->row_segments.back().second == c.row_off + i * c.g_dim)
                     h->row_segments.back().second += c.g_dim;
@@ -1126,6 +1220,15 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 c.k.tidx = own(h, dupload(tidx));
                 c.k.hess_on = own(h, dupload(hess_on));
                 c.k.jpos = own(h, dupload(jpos));
+                if (c.external) {  // Hessian blocks: knot constraints place knot entries, the global one tail entries
+                    c.xk.nc = c.global ? 0 : (int32_t)c.comps.size();
+                    c.xk.ng = c.global ? (int32_t)c.comps.size() : 0;
+                    c.xk.comps = c.k.comps; c.xk.gcomps = c.k.comps;
+                    c.xk.times = c.k.times; c.xk.tidx = c.k.tidx;
+                    c.xk.knot_on = c.k.hess_on; c.xk.count = c.k.hess_on;
+                    c.xk.glob_on = h->k_hi == h->N ? 1 : 0;
+                    c.xk.n_list = c.k.n_times;
+                }
             }
         }
         h->cons_len = lrow;
@@ -1133,8 +1236,6 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         I.n_row_segments = (int32_t)h->row_segments.size();
 
         // objectives
-        for (int i = 0; i < d->n_objectives; ++i)
-            if (d->objectives[i].kind == DTO_OBJECTIVE_EXTERNAL_KNOT) h->n_ext_obj++;
         for (int i = 0; i < d->n_objectives && !sonly; ++i) {
             const dto_objective_desc& s = d->objectives[i];
             KObj o{};
@@ -1190,45 +1291,47 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 o.Qs = own(h, dupload(Qs));
                 o.last = own(h, dupload(last));
                 o.params = s.params ? own(h, dupload(params)) : nullptr;
-            } else if (s.kind == DTO_OBJECTIVE_EXTERNAL_KNOT) {
-                if (s.n_comps < 1 || !s.comps || !s.times) throw HipError{"external knot objective: comps and times are required"};
-                std::vector<int32_t> comps(s.comps, s.comps + s.n_comps);
-                for (int q : comps)
-                    if (q < 0 || q >= d->z) throw HipError{"external knot objective: component out of range"};
-                std::vector<int64_t> tix;
-                std::vector<int32_t> last;
-                for (int64_t t = 0; t < s.n_times; ++t) {
-                    if (s.times[t] < 1 || s.times[t] > d->N) throw HipError{"objective: time out of range"};
-                    const int64_t kn = s.times[t] - 1;
-                    if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) continue;
-                    times.push_back(kn);
-                    tix.push_back(t);
-                    int32_t is_last = 1;
-                    for (int64_t t2 = t + 1; t2 < s.n_times; ++t2)
-                        if (s.times[t2] == s.times[t]) { is_last = 0; break; }
-                    last.push_back(is_last);
-                }
-                ExtObjHost e;
-                e.n_comps = s.n_comps; e.weight = s.weight;
-                e.n_times = (int64_t)times.size(); e.n_times_total = s.n_times;
-                e.comps = own(h, dupload(comps));
-                e.times = own(h, dupload(times));
-                e.tidx = own(h, dupload(tix));
-                e.last = own(h, dupload(last));
-                e.ext_slot = (int)h->ext.size();
-                ExtSlot sl;
-                sl.len[0] = (size_t)s.n_times;
-                sl.len[1] = (size_t)s.n_comps * s.n_times;
-                sl.len[2] = (size_t)s.n_comps * s.n_comps * s.n_times;
-                h->ext.push_back(sl);
-                h->ext_obj.push_back(e);
-                continue;
+            } else if (s.kind == DTO_OBJECTIVE_EXTERNAL_KNOT || s.kind == DTO_OBJECTIVE_EXTERNAL_GLOBAL) {
+                continue;  // placed by the external-term kernels (set up below)
             } else {
                 throw HipError{"unknown objective kind"};
             }
             o.n_times = (int64_t)times.size();
             o.times = own(h, dupload(times));
             h->obj.push_back(o);
+        }
+
+        // host-evaluated objective terms: which listings this handle places (knot part: the knot's owner; entries in
+        // global-variable columns and listings without a knot part: the rank that owns the last knot)
+        const bool last_rank = h->k_hi == h->N;
+        for (auto& e : h->ext_obj) {
+            std::vector<int64_t> times, tix;
+            std::vector<int32_t> knot_on, count;
+            for (size_t i = 0; i < e.times0.size(); ++i) {
+                const int64_t kn = e.times0[i];
+                const bool pseudo = kn >= h->N;
+                const bool own = pseudo ? last_rank : (kn >= P.kn_lo && kn < P.kn_lo + P.n_knots);
+                if (!own && !(e.global && last_rank)) continue;
+                int32_t on = own && !pseudo;
+                if (on && !e.global)  // KnotPointObjective's gradient!/hessian! overwrite per listing: the last one wins
+                    for (size_t i2 = i + 1; i2 < e.times0.size(); ++i2)
+                        if (e.times0[i2] == kn) { on = 0; break; }
+                times.push_back(kn);
+                tix.push_back((int64_t)i);
+                knot_on.push_back(on);
+                count.push_back(own ? 1 : 0);
+            }
+            e.k.nc = (int32_t)e.comps.size(); e.k.ng = (int32_t)e.gcomps.size();
+            e.k.n_list = (int64_t)times.size();
+            e.k.glob_on = last_rank ? 1 : 0;
+            if (!sonly) {
+                e.k.comps = own(h, dupload(e.comps));
+                e.k.gcomps = own(h, dupload(e.gcomps));
+                e.k.times = own(h, dupload(times));
+                e.k.tidx = own(h, dupload(tix));
+                e.k.knot_on = own(h, dupload(knot_on));
+                e.k.count = own(h, dupload(count));
+            }
         }
 
         if (sonly) {
@@ -1372,6 +1475,15 @@ int dto_jacobian_structure(const dto_handle* h, int64_t first, int64_t count, in
         }
         for (size_t e = con_lower(h, c); e < h->con_cols.size() && h->con_cols[e] == c; ++e) emit(h->con_rows[e]);
     }
+    for (; c < h->n_vars && written < count; ++c) {  // global-variable columns: NonlinearGlobalConstraint rows only
+        int64_t pos = h->colptr[c];
+        for (size_t e = con_lower(h, c); e < h->con_cols.size() && h->con_cols[e] == c; ++e, ++pos)
+            if (pos >= first && written < count) {
+                rows[written] = h->con_rows[e] + 1;
+                cols[written] = c + 1;
+                ++written;
+            }
+    }
     return written == count ? 0 : 1;
 }
 
@@ -1397,6 +1509,13 @@ int dto_hessian_structure(const dto_handle* h, int64_t first, int64_t count, int
             for (int a = 0; a <= b; ++a) emit(kn * z + a);
         }
     }
+    for (int j = 0; j < h->gd && written < count; ++j)  // tail: global-variable columns
+        for (int64_t e = h->tail_colptr[j]; e < h->tail_colptr[j + 1] && written < count; ++e)
+            if (h->hess_block_nnz + e >= first) {
+                rows[written] = h->tail_rows[e] + 1;
+                cols[written] = h->N * z + j + 1;
+                ++written;
+            }
     return written == count ? 0 : 1;
 }
 
@@ -1563,7 +1682,7 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
     double* o = staging(h, (size_t)n_out);
     HIP_CHECK(hipMemsetAsync(o, 0, sizeof(double) * (size_t)n_out, h->stream));  // fill!(y, 0), evaluator.jl:416,442
     if (T.n > 0 || !h->con.empty())
-        launch_jac_spmv(h->stream, h->P, T, h->d_conbase, h->d_con_rows, h->d_jac_scratch, h->d_w, o, transpose);
+        launch_jac_spmv(h->stream, h->P, T, h->d_conbase, h->d_con_rows, h->d_jac_scratch, h->d_w, o, transpose, h->gd);
     HIP_CHECK(hipMemcpyAsync(y, o, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     check_sweeps(h);

@@ -25,7 +25,22 @@ struct KProb {
     int64_t jac_lo;     // first Jacobian value owned
     int64_t hess_lo;    // first Hessian value owned
     int64_t grad_lo;    // first gradient entry owned (= kn_lo*z)
+    // Hessian entries in global-variable columns (the tail of the CSC order; only host-evaluated Global* terms have any)
+    const int64_t* tail_colptr;  // device [gd+1]
+    const int64_t* tail_rows;    // device, 0-based global row indices, ascending per column
+    int64_t tail_lo;             // local position of the tail's first value in this handle's slab, -1: not owned
 };
+
+// position of entry (global row R, global-variable column j) in the local Hessian slab, -1 if absent / not owned
+__host__ __device__ inline int64_t hess_pos_tail(const KProb& P, int64_t R, int j) {
+    if (P.tail_lo < 0) return -1;
+    int64_t lo = P.tail_colptr[j], hi = P.tail_colptr[j + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (P.tail_rows[mid] < R) lo = mid + 1; else hi = mid;
+    }
+    return (lo < P.tail_colptr[j + 1] && P.tail_rows[lo] == R) ? P.tail_lo + lo : -1;
+}
 
 // One BilinearIntegrator (src/integrators/bilinear_integrator.jl:61-85) on the device.
 struct KBil {
@@ -192,12 +207,23 @@ void launch_extint_hess(hipStream_t st, const KProb& P, const KExtInt& E, const 
 // host-evaluated knot terms (DTO_CONSTRAINT_EXTERNAL / DTO_OBJECTIVE_EXTERNAL_KNOT): scatter of caller-supplied blocks
 void launch_ext_cons(hipStream_t st, const KCon& C, const double* vals, double* g);
 void launch_ext_jac(hipStream_t st, const KCon& C, const double* blocks, double* vals);
-// H[pos(kn, comps[a], comps[b])] += scale * block[tidx][a + nc*b] for comps[a] <= comps[b], where on[ti] != 0
-void launch_ext_hess(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
-                     const int32_t* on, int64_t n_times, double scale, const double* blocks, double* H);
-void launch_ext_objective(hipStream_t st, const int64_t* tidx, int64_t n_times, double weight, const double* vals, double* f);
-void launch_ext_gradient(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
-                         const int32_t* on, int64_t n_times, double weight, const double* blocks, double* grad);
+// One host-evaluated term's placement data: per listing i the variables [z_t[comps] ; global_data[gcomps]]
+// (times[i] == N: no knot part).  `knot_on` / `glob_on`: this handle places the listing's knot part / its entries in
+// global-variable columns; `count`: this handle adds the listing's value to the objective.
+struct KExtTerm {
+    int32_t nc, ng;
+    const int32_t* comps;    // device [nc]
+    const int32_t* gcomps;   // device [ng]
+    const int64_t* times;    // device [n_list] 0-based knots
+    const int64_t* tidx;     // device [n_list] index of the listing in the caller's arrays
+    const int32_t* knot_on;  // device [n_list]
+    const int32_t* count;    // device [n_list]
+    int32_t glob_on, pad;
+    int64_t n_list;
+};
+void launch_ext_hess(hipStream_t st, const KProb& P, const KExtTerm& E, double scale, const double* blocks, double* H);
+void launch_ext_objective(hipStream_t st, const KExtTerm& E, double weight, const double* vals, double* f);
+void launch_ext_gradient(hipStream_t st, const KProb& P, const KExtTerm& E, double weight, const double* blocks, double* grad);
 
 struct KObj {  // objective term
     int32_t kind, comp_off, comp_dim, has_baseline;
@@ -237,7 +263,7 @@ struct KIntegTable {
     int64_t off[8];
 };
 void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
-                     const double* vals, const double* w, double* y, int transpose);
+                     const double* vals, const double* w, double* y, int transpose, int64_t global_cols = 0);
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n);  // dst += src
 
 // Powers of A_k from the generator subspace: A_k = dt*sum_j ubar_j G_j lives in an (m+1)-dimensional

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64) k_jac_spmv(KProb P, KIntegTable T, const i
     const int64_t cl = blockIdx.x;                 // local column
     const int64_t c = P.kn_lo * P.z + cl;          // global column
     const int64_t kn = c / P.z;
-    const int has_prev = kn >= 1, has_own = kn < P.K;
+    const int has_prev = kn >= 1 && kn < P.N, has_own = kn < P.K;  // kn >= N: global-variable columns (constraint rows only)
     const int cnt = has_prev + has_own;
     const int64_t e0 = P.colptr[c], e1 = P.colptr[c + 1];
     const int64_t Lint = (int64_t)P.D * cnt;
@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(64) k_jac_spmv(KProb P, KIntegTable T, const i
     }
 }
 void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
-                     const double* vals, const double* w, double* y, int transpose) {
-    const int64_t ncols = P.n_knots * P.z;
+                     const double* vals, const double* w, double* y, int transpose, int64_t global_cols) {
+    const int64_t ncols = P.n_knots * P.z + global_cols;
     if (ncols <= 0) return;
     if (transpose) hipLaunchKernelGGL(k_jac_spmv<1>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
     else hipLaunchKernelGGL(k_jac_spmv<0>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
@@ -1611,56 +1611,61 @@ void launch_ext_jac(hipStream_t st, const KCon& C, const double* blocks, double*
     hipLaunchKernelGGL(k_ext_jac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, C, blocks, vals);
 }
 
-__global__ void k_ext_hess(KProb P, int nc, const int32_t* __restrict__ comps, const int64_t* __restrict__ times,
-                           const int64_t* __restrict__ tidx, const int32_t* __restrict__ on, int64_t n_times, double scale,
-                           const double* __restrict__ blocks, double* __restrict__ H) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nc2 = nc * nc;
-    if (i >= n_times * nc2) return;
-    const int64_t ti = i / nc2;
-    if (!on[ti]) return;
-    const int b = (int)((i % nc2) / nc), a = (int)(i % nc);  // column-major block: element (a, b)
-    const int ca = comps[a], cb = comps[b];
-    if (ca > cb) return;  // row <= col (evaluator.jl:637)
-    const double v = scale * blocks[tidx[ti] * nc2 + (i % nc2)];
-    if (v != 0.0) atomicAdd(&H[hess_pos(P, times[ti], ca, cb)], v);
+// global variable index of block element a of listing ti: knot part first, then the global variables
+__device__ __forceinline__ int64_t ext_var(const KProb& P, const KExtTerm& E, int64_t ti, int a) {
+    return a < E.nc ? E.times[ti] * P.z + E.comps[a] : P.N * P.z + E.gcomps[a - E.nc];
 }
-void launch_ext_hess(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
-                     const int32_t* on, int64_t n_times, double scale, const double* blocks, double* H) {
-    const int64_t n = n_times * n_comps * n_comps;
+// H[row <= col entries of the listing's block] += scale * block (column-major nb x nb, nb = nc + ng)
+__global__ void k_ext_hess(KProb P, KExtTerm E, double scale, const double* __restrict__ blocks, double* __restrict__ H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = E.nc + E.ng, nb2 = nb * nb;
+    if (i >= E.n_list * nb2) return;
+    const int64_t ti = i / nb2;
+    const int b = (int)((i % nb2) / nb), a = (int)(i % nb);  // element (a, b)
+    const int64_t R = ext_var(P, E, ti, a), C = ext_var(P, E, ti, b);
+    if (R > C) return;  // row <= col (evaluator.jl:637)
+    const double v = scale * blocks[E.tidx[ti] * nb2 + (i % nb2)];
+    if (v == 0.0) return;
+    if (b < E.nc) {  // knot column: both indices in knot times[ti]
+        if (E.knot_on[ti]) atomicAdd(&H[hess_pos(P, E.times[ti], E.comps[a], E.comps[b])], v);
+    } else if (E.glob_on) {
+        const int64_t p = hess_pos_tail(P, R, E.gcomps[b - E.nc]);
+        if (p >= 0) atomicAdd(&H[p], v);
+    }
+}
+void launch_ext_hess(hipStream_t st, const KProb& P, const KExtTerm& E, double scale, const double* blocks, double* H) {
+    const int64_t nb = E.nc + E.ng, n = E.n_list * nb * nb;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_ext_hess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n_comps, comps, times, tidx, on, n_times, scale, blocks, H);
+    hipLaunchKernelGGL(k_ext_hess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, E, scale, blocks, H);
 }
 
-// f += weight * sum of the owned times' values, fixed order within the block (deterministic)
-__global__ void __launch_bounds__(256) k_ext_objective(const int64_t* __restrict__ tidx, int64_t n_times, double weight,
-                                                        const double* __restrict__ vals, double* f) {
+// f += weight * sum of the counted listings' values, fixed order within the block (deterministic)
+__global__ void __launch_bounds__(256) k_ext_objective(KExtTerm E, double weight, const double* __restrict__ vals, double* f) {
     __shared__ double sm[4];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n_times; i += 256) acc += vals[tidx[i]];
+    for (int64_t i = threadIdx.x; i < E.n_list; i += 256)
+        if (E.count[i]) acc += vals[E.tidx[i]];
     const double tot = block_sum_256(acc, sm);
     if (threadIdx.x == 0) *f += weight * tot;
 }
-void launch_ext_objective(hipStream_t st, const int64_t* tidx, int64_t n_times, double weight, const double* vals, double* f) {
-    if (n_times <= 0) return;
-    hipLaunchKernelGGL(k_ext_objective, dim3(1), dim3(256), 0, st, tidx, n_times, weight, vals, f);
+void launch_ext_objective(hipStream_t st, const KExtTerm& E, double weight, const double* vals, double* f) {
+    if (E.n_list <= 0) return;
+    hipLaunchKernelGGL(k_ext_objective, dim3(1), dim3(256), 0, st, E, weight, vals, f);
 }
 
-__global__ void k_ext_gradient(KProb P, int nc, const int32_t* __restrict__ comps, const int64_t* __restrict__ times,
-                               const int64_t* __restrict__ tidx, const int32_t* __restrict__ on, int64_t n_times, double weight,
-                               const double* __restrict__ blocks, double* __restrict__ grad) {
+__global__ void k_ext_gradient(KProb P, KExtTerm E, double weight, const double* __restrict__ blocks, double* __restrict__ grad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_times * nc) return;
-    const int64_t ti = i / nc;
-    if (!on[ti]) return;
-    const int c = (int)(i % nc);
-    atomicAdd(&grad[times[ti] * P.z + comps[c] - P.grad_lo], weight * blocks[tidx[ti] * nc + c]);
+    const int nb = E.nc + E.ng;
+    if (i >= E.n_list * nb) return;
+    const int64_t ti = i / nb;
+    const int a = (int)(i % nb);
+    if (a < E.nc ? !E.knot_on[ti] : !E.glob_on) return;
+    atomicAdd(&grad[ext_var(P, E, ti, a) - P.grad_lo], weight * blocks[E.tidx[ti] * nb + a]);
 }
-void launch_ext_gradient(hipStream_t st, const KProb& P, int n_comps, const int32_t* comps, const int64_t* times, const int64_t* tidx,
-                         const int32_t* on, int64_t n_times, double weight, const double* blocks, double* grad) {
-    const int64_t n = n_times * n_comps;
+void launch_ext_gradient(hipStream_t st, const KProb& P, const KExtTerm& E, double weight, const double* blocks, double* grad) {
+    const int64_t n = E.n_list * (E.nc + E.ng);
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_ext_gradient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, n_comps, comps, times, tidx, on, n_times, weight, blocks, grad);
+    hipLaunchKernelGGL(k_ext_gradient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, E, weight, blocks, grad);
 }
 
 // Bilinear block of mu_k' f  (bilinear_integrator.jl:135-161).  With y = exp(A)x, c_j = dexp(A)[dt G_j]x,

@@ -10,8 +10,8 @@ c_int32_p = C.POINTER(C.c_int32)
 
 DTO_ABI_VERSION = 3
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL = 1, 2, 3
-OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK = 1, 2, 3, 4, 5, 6
-CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL = 1, 2, 3
+OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK, OBJECTIVE_EXTERNAL_GLOBAL = 1, 2, 3, 4, 5, 6, 7
+CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL, CONSTRAINT_EXTERNAL_GLOBAL = 1, 2, 3, 4
 
 
 class IntegratorDesc(C.Structure):
@@ -23,13 +23,14 @@ class ObjectiveDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("comp_off", C.c_int32), ("comp_dim", C.c_int32), ("reserved", C.c_int32),
                 ("weight", C.c_double), ("D", C.c_double), ("R", c_double_p), ("baseline", c_double_p),
                 ("times", c_int64_p), ("n_times", C.c_int64), ("comps", c_int32_p), ("n_comps", C.c_int32),
-                ("reserved2", C.c_int32), ("params", c_double_p), ("Qs", c_double_p)]
+                ("reserved2", C.c_int32), ("params", c_double_p), ("Qs", c_double_p),
+                ("gcomps", c_int32_p), ("n_gcomps", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class ConstraintDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("equality", C.c_int32), ("n_comps", C.c_int32), ("g_dim", C.c_int32),
                 ("comps", c_int32_p), ("c", C.c_double), ("times", c_int64_p), ("n_times", C.c_int64),
-                ("jac0", c_double_p)]
+                ("jac0", c_double_p), ("hess0", c_double_p)]
 
 
 class ExternalValues(C.Structure):

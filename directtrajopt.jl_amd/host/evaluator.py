@@ -8,8 +8,9 @@ import numpy as np
 
 from . import capi
 from .capi import library_path, load_library  # noqa: F401
-from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, HostIntegrator, KnotPointObjective, LinearRegularizer,
-                      MinimumTimeObjective, NonlinearKnotPointConstraint, NullObjective, QuadraticRegularizer)
+from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, GlobalKnotPointObjective, HostIntegrator,
+                      KnotPointObjective, LinearRegularizer, MinimumTimeObjective, NonlinearGlobalConstraint,
+                      NonlinearKnotPointConstraint, NullObjective, QuadraticRegularizer)
 
 
 class EngineError(RuntimeError):
@@ -92,6 +93,18 @@ class Evaluator:
                     t = np.ascontiguousarray(o.times, dtype=np.int64)
                     keep.append(t)
                     d.times, d.n_times = _ip(t), t.size
+            elif isinstance(o, GlobalKnotPointObjective):  # incl. GlobalObjective
+                d.kind = capi.OBJECTIVE_EXTERNAL_GLOBAL
+                comps = np.ascontiguousarray(o.comps, dtype=np.int32)
+                gcomps = np.ascontiguousarray(o.gcomps, dtype=np.int32)
+                t = np.ascontiguousarray(o.times, dtype=np.int64)
+                keep += [comps, gcomps, t]
+                if comps.size:
+                    d.comps, d.n_comps = comps.ctypes.data_as(capi.c_int32_p), comps.size
+                d.gcomps, d.n_gcomps = gcomps.ctypes.data_as(capi.c_int32_p), gcomps.size
+                if t.size:
+                    d.times, d.n_times = _ip(t), t.size
+                self._ext_obj.append(o)
             elif isinstance(o, KnotPointObjective) and o.external:
                 d.kind = capi.OBJECTIVE_EXTERNAL_KNOT
                 comps = np.ascontiguousarray(o.comps, dtype=np.int32)
@@ -121,10 +134,19 @@ class Evaluator:
                 raise NotImplementedError(f"{type(o).__name__} stays on the host (closure-based objective)")
             objs[i] = d
 
-        nl = [c for c in prob.constraints if isinstance(c, NonlinearKnotPointConstraint)]
+        nl = [c for c in prob.constraints if isinstance(c, (NonlinearKnotPointConstraint, NonlinearGlobalConstraint))]
         self._nl_constraints = nl
         cons = (capi.ConstraintDesc * max(1, len(nl)))()
         for i, c in enumerate(nl):
+            if isinstance(c, NonlinearGlobalConstraint):
+                gcomps = np.ascontiguousarray(c.gcomps, dtype=np.int32)
+                _, jac0, hess0 = c.external_blocks(None, 2, mu=np.ones(c.g_dim), g=traj.global_data)  # patterns at Z0, mu = ones
+                jac0, hess0 = np.ascontiguousarray(jac0), np.ascontiguousarray(hess0)
+                keep += [gcomps, jac0, hess0]
+                cons[i] = capi.ConstraintDesc(capi.CONSTRAINT_EXTERNAL_GLOBAL, int(c.equality), gcomps.size, c.g_dim,
+                                              gcomps.ctypes.data_as(capi.c_int32_p), 0.0, None, 0, _dp(jac0), _dp(hess0))
+                self._ext_con.append(c)
+                continue
             comps = np.ascontiguousarray(c.comps, dtype=np.int32)
             t = np.ascontiguousarray(c.times, dtype=np.int64)
             keep += [comps, t]
@@ -134,11 +156,11 @@ class Evaluator:
                 jac0 = np.ascontiguousarray(c.external_blocks(Zk0, 1)[1])
                 keep.append(jac0)
                 cons[i] = capi.ConstraintDesc(capi.CONSTRAINT_EXTERNAL, int(c.equality), comps.size, c.g_dim,
-                                              comps.ctypes.data_as(capi.c_int32_p), 0.0, _ip(t), t.size, _dp(jac0))
+                                              comps.ctypes.data_as(capi.c_int32_p), 0.0, _ip(t), t.size, _dp(jac0), None)
                 self._ext_con.append(c)
                 continue
             cons[i] = capi.ConstraintDesc(NonlinearKnotPointConstraint.KINDS[c.kind], int(c.equality), comps.size, 1,
-                                          comps.ctypes.data_as(capi.c_int32_p), c.c, _ip(t), t.size, None)
+                                          comps.ctypes.data_as(capi.c_int32_p), c.c, _ip(t), t.size, None, None)
 
         Z0 = np.ascontiguousarray(traj.vec(), dtype=np.float64)
         desc = capi.ProblemDesc(capi.DTO_ABI_VERSION, device, traj.N, traj.dim, traj.global_dim,
@@ -199,6 +221,7 @@ class Evaluator:
             raise EngineError("closure-based terms need the host copy of Z (pass Z_host to the *_dev call)")
         traj = self.trajectory
         Zk = np.asarray(Z, dtype=np.float64)[:traj.dim * traj.N].reshape(traj.N, traj.dim)
+        gdat = np.asarray(Z, dtype=np.float64)[traj.dim * traj.N:]
         ni = len(self._ext_int)
         vals = (capi.ExternalValues * (ni + len(self._ext_con) + len(self._ext_obj)))()
         keep = []
@@ -220,7 +243,8 @@ class Evaluator:
             if con_need < 0:
                 continue
             m = None if mu is None else np.asarray(mu, dtype=np.float64)[rows[id(c)]:rows[id(c)] + c.dim]
-            blocks = c.external_blocks(Zk, con_need, m)
+            blocks = (c.external_blocks(Zk, con_need, m, g=gdat) if isinstance(c, NonlinearGlobalConstraint)
+                      else c.external_blocks(Zk, con_need, m))
             for name, b in zip(("values", "first", "second"), blocks):
                 if b is not None:
                     b = np.ascontiguousarray(b, dtype=np.float64)
@@ -229,7 +253,8 @@ class Evaluator:
         for j, o in enumerate(self._ext_obj):
             if obj_need < 0:
                 continue
-            blocks = o.external_blocks(Zk, obj_need)
+            blocks = (o.external_blocks(Zk, obj_need, g=gdat) if isinstance(o, GlobalKnotPointObjective)
+                      else o.external_blocks(Zk, obj_need))
             for name, b in zip(("values", "first", "second"), blocks):
                 if b is not None:
                     b = np.ascontiguousarray(b, dtype=np.float64)

@@ -266,6 +266,98 @@ class KnotPointObjective(AbstractObjective):
         return vals, first, second
 
 
+class GlobalKnotPointObjective(AbstractObjective):
+    """GlobalKnotPointObjective(l, names, global_names, traj, params; times, Qs) --
+    src/objectives/global_objectives.jl:151-206: J = sum_i Q_i l([z_{t_i}[names]; global_data[global_names]], p_i).
+    Host-evaluated (a closure) and merged by the engine; gradient and Hessian accumulate over the listings."""
+
+    external = True
+    is_global = True
+
+    def __init__(self, l, names, global_names, traj, params=None, times=None, Qs=None, grad=None, hess=None):
+        names = [names] if isinstance(names, str) else list(names)
+        if global_names is None:
+            global_names = list(traj.global_components.keys())  # auto-detect, :171-174
+        global_names = [global_names] if isinstance(global_names, str) else list(global_names)
+        self.l, self.grad, self.hess = l, grad, hess
+        self.var_names, self.global_names = names, global_names
+        self.times = _times(range(1, traj.N + 1) if times is None else times, traj.N)
+        self.comps = (np.concatenate([np.asarray(traj.components[n]) for n in names]).astype(np.int32)
+                      if names else np.zeros(0, dtype=np.int32))
+        self.gcomps = np.concatenate([np.asarray(traj.global_components[n]) for n in global_names]).astype(np.int32)
+        nt = self.times.size
+        self.Qs = np.ones(nt) if Qs is None else np.asarray(Qs, dtype=np.float64)
+        self.params = [None] * nt if params is None else list(params)
+        if self.Qs.shape != (nt,) or len(self.params) != nt:
+            raise ValueError("Qs and params must have the same length as times")
+
+    def _listings(self, Zk, g):
+        return [np.concatenate([Zk[t - 1, self.comps], g[self.gcomps]]) for t in self.times]
+
+    def external_blocks(self, Zk, need, g=None):
+        from . import closures
+        vs = self._listings(Zk, g)
+        nl, nb = len(vs), self.comps.size + self.gcomps.size
+        vals = np.zeros(nl)
+        first = np.zeros((nl, nb)) if need >= 1 else None
+        second = np.zeros((nl, nb, nb)) if need >= 2 else None
+        for i, v in enumerate(vs):
+            p, Q = self.params[i], self.Qs[i]
+            vals[i] = Q * float(self.l(v, p))
+            if need >= 1:
+                first[i] = Q * closures.gradient(self.l, v, p, self.grad)
+            if need >= 2:
+                second[i] = Q * closures.hessian(lambda x: self.l(x, p), v,
+                                                 None if self.grad is None else (lambda x: self.grad(x, p)),
+                                                 None if self.hess is None else (lambda x: self.hess(x, p))).T
+        return vals, first, second
+
+
+class GlobalObjective(GlobalKnotPointObjective):
+    """GlobalObjective(l, global_names, traj; Q) -- global_objectives.jl:35-52: J = Q l(global_data[global_names])."""
+
+    def __init__(self, l, global_names, traj, Q=1.0, grad=None, hess=None):
+        super().__init__((lambda v, p: l(v)), [], global_names, traj, params=[None], times=[1], Qs=[float(Q)],
+                         grad=None if grad is None else (lambda v, p: grad(v)),
+                         hess=None if hess is None else (lambda v, p: hess(v)))
+        self.times = np.zeros(0, dtype=np.int64)  # no knot part: one listing of the global variables alone
+
+    def _listings(self, Zk, g):
+        return [g[self.gcomps]]
+
+
+class NonlinearGlobalConstraint:
+    """NonlinearGlobalConstraint(g, global_names, traj; equality) --
+    src/constraints/nonlinear/global_constraint.jl:20-75: g(global_data[global_names]) = 0 or <= 0.  Host-evaluated and
+    merged; its Jacobian/Hessian entries live in the global-variable columns."""
+
+    external = True
+    is_global = True
+
+    def __init__(self, g, global_names, traj, equality=True, jac=None, hess=None):
+        global_names = [global_names] if isinstance(global_names, str) else list(global_names)
+        self.g, self.jac, self.hess, self.equality = g, jac, hess, bool(equality)
+        self.global_names = global_names
+        self.gcomps = np.concatenate([np.asarray(traj.global_components[n]) for n in global_names]).astype(np.int32)
+        self.global_dim = self.gcomps.size
+        self.g_dim = int(np.asarray(g(traj.global_data[self.gcomps])).size)
+        self.dim = self.g_dim
+
+    def external_blocks(self, Zk, need, mu=None, g=None):
+        from . import closures
+        v, gd, ng = g[self.gcomps], self.g_dim, self.gcomps.size
+        vals = np.asarray(self.g(v), dtype=np.float64).reshape(gd)
+        first = second = None
+        if need >= 1:
+            first = closures.jacobian(lambda x, p: self.g(x), v, None, gd, None if self.jac is None else (lambda x, p: self.jac(x))).T
+        if need >= 2:
+            m = np.ones(gd) if mu is None else np.asarray(mu, dtype=np.float64)
+            second = closures.hessian(lambda x: m @ np.asarray(self.g(x)).reshape(gd), v,
+                                      None if self.jac is None else (lambda x: m @ np.asarray(self.jac(x)).reshape(gd, ng)),
+                                      None if self.hess is None else (lambda x: self.hess(x, m))).T
+        return vals, first, second
+
+
 def ket_fidelity_factor(goal_iso):
     """A (2 x 2n) with ||A psi~||^2 = |<goal|psi>|^2 for iso vectors psi~ = [Re psi; Im psi]."""
     g = np.asarray(goal_iso, dtype=np.float64)

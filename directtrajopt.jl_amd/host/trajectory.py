@@ -10,7 +10,7 @@ import numpy as np
 
 
 class NamedTrajectory:
-    def __init__(self, components, timestep, global_data=None):
+    def __init__(self, components, timestep, global_data=None, global_components=None):
         """components: ordered mapping name -> array (dim_i x N); timestep: name of the timestep
         COMPONENT (the integrators read ``traj.components[traj.timestep]``,
         bilinear_integrator.jl:123, so a fixed Float timestep is rejected)."""
@@ -35,6 +35,14 @@ class NamedTrajectory:
         self.data = np.vstack(arrays)
         self.global_data = np.zeros(0) if global_data is None else np.asarray(global_data, dtype=np.float64).ravel()
         self.global_dim = self.global_data.size
+        # NamedTrajectories' `global_components`: name -> indices into global_data (one unnamed block by default)
+        if global_components is None:
+            self.global_components = OrderedDict([("globals", range(self.global_dim))]) if self.global_dim else OrderedDict()
+        else:
+            self.global_components = OrderedDict((k, list(v)) for k, v in global_components.items())
+            for v in self.global_components.values():
+                if any(i < 0 or i >= self.global_dim for i in v):
+                    raise ValueError("global component index out of range")
 
     @property
     def datavec(self):

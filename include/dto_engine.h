@@ -54,6 +54,12 @@ extern "C" {
                                                  coordinates, whose per-knot Hessian is the ConstantLowRankHVP
                                                  shape A' G A with G = -2 sign(1 - F) I (knot_hvp.jl:45-84).
                                                  A is passed in `R` (k x n_comps column-major), k in `comp_dim` */
+#define DTO_OBJECTIVE_EXTERNAL_GLOBAL 7         /* GlobalObjective / GlobalKnotPointObjective (global_objectives.jl:35-350),
+                                                 host closure over [z_t[comps]; global_data[gcomps]] per listed time
+                                                 (n_times = 0: one listing of the global variables alone).  Gradient
+                                                 and Hessian blocks ACCUMULATE over the listings (:270-271, :341), the
+                                                 Hessian entries whose column is a global variable form the tail of
+                                                 the CSC order (global columns follow all knot columns) */
 #define DTO_OBJECTIVE_EXTERNAL_KNOT 5         /* KnotPointObjective / TerminalObjective with a HOST closure l: the
                                                  caller evaluates Q_i l, its gradient and Hessian per listed time
                                                  (the reference's own ForwardDiff code, knot_point_objectives.jl:
@@ -63,6 +69,10 @@ extern "C" {
 /* built-in g kinds for NonlinearKnotPointConstraint (knot_point_constraint.jl:27-107) */
 #define DTO_CONSTRAINT_NORM_MINUS_C 1   /* g(v) = [ ||v||_2   - c ] */
 #define DTO_CONSTRAINT_SQNORM_MINUS_C 2 /* g(v) = [ ||v||_2^2 - c ] */
+#define DTO_CONSTRAINT_EXTERNAL_GLOBAL 4 /* NonlinearGlobalConstraint g(global_data[comps]) with g_dim outputs
+                                           (global_constraint.jl:20-160): host closure; `comps` index global_data,
+                                           `times` is unused; patterns = non-zeros of `jac0` (g_dim x n_comps) and
+                                           of `hess0` (n_comps x n_comps, mu = ones; evaluator.jl:166) */
 #define DTO_CONSTRAINT_EXTERNAL 3       /* host closure g with g_dim outputs: values, Jacobian blocks and
                                            mu-weighted Hessian blocks come from the caller (dto_set_external),
                                            evaluated with the reference's own code (knot_point_constraint.jl:
@@ -95,6 +105,9 @@ typedef struct dto_objective_desc {
     int32_t reserved2;
     const double* params;   /* n_comps x n_times column-major targets p_i, or NULL = zeros */
     const double* Qs;       /* n_times weights Q_i, or NULL = ones */
+    const int32_t* gcomps;  /* EXTERNAL_GLOBAL: indices into global_data (0-based), vcat of global_names comps */
+    int32_t n_gcomps;
+    int32_t reserved3;
 } dto_objective_desc;
 
 typedef struct dto_constraint_desc {
@@ -108,6 +121,7 @@ typedef struct dto_constraint_desc {
     int64_t n_times;
     const double* jac0;     /* EXTERNAL only: Jacobian blocks at Z0, [n_times] blocks g_dim x n_comps column-major;
                                entries that are exactly 0.0 are outside the pattern (evaluator.jl:136) */
+    const double* hess0;    /* EXTERNAL_GLOBAL only: Hessian of sum(g) at Z0, n_comps x n_comps column-major */
 } dto_constraint_desc;
 
 typedef struct dto_problem_desc {
@@ -179,6 +193,8 @@ int dto_constraint_bounds(const dto_handle* h, double* lower, double* upper);
  *               like every integrator block (evaluator.jl:574-598), row <= col entries only
  *   constraint: values = g, [n_times] x g_dim;  first = Jacobian blocks, [n_times] x (g_dim x n_comps col-major);
  *               second = Hessian blocks of mu_i' g, [n_times] x (n_comps x n_comps col-major)
+ *   global constraint: values = g [g_dim]; first = Jacobian g_dim x n_comps col-major; second = Hessian of mu' g
+ *   global objective:  as "objective" below with v_i = [z_t[comps]; global_data[gcomps]] (block size n_comps + n_gcomps)
  *   objective:  values = Q_i l(v_i, p_i), [n_times];  first = Q_i grad l, [n_times] x n_comps;
  *               second = Q_i Hessian of l, [n_times] x (n_comps x n_comps col-major)
  * Semantics follow the reference: Jacobian entries are assigned, outside-pattern entries dropped

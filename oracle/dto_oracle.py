@@ -188,6 +188,49 @@ class ClosureKnotConstraint:
 
 
 @dataclass
+class GlobalClosureConstraint:
+    """NonlinearGlobalConstraint g(global_data[gcomps]) (src/constraints/nonlinear/global_constraint.jl:20-160) with
+    analytic jac(v) -> (g_dim, ng) and hess(v, mu) -> (ng, ng) standing in for ForwardDiff (:126-158)."""
+
+    g: object
+    jac: object
+    hess: object
+    gcomps: Sequence[int]
+    g_dim: int
+    equality: bool = True
+
+    kind = "global_closure"
+    times1 = (0,)  # one row block (row counting shares the knot-constraint code)
+
+
+@dataclass
+class GlobalClosureObjective:
+    """GlobalObjective (times1 empty: Q l(g)) / GlobalKnotPointObjective (sum_i Q_i l([z_t[comps]; g], p_i)) of
+    src/objectives/global_objectives.jl:35-350, g = global_data[gcomps]; analytic grad(v, p), hess(v, p).  Unlike
+    KnotPointObjective, gradient and Hessian ACCUMULATE over the listings (:270-271, :341)."""
+
+    l: object
+    grad: object
+    hess: object
+    comps: Sequence[int]
+    gcomps: Sequence[int]
+    times1: Sequence[int]
+    Qs: Sequence[float]
+    params: Optional[Sequence[object]] = None
+
+    kind = "global_closure"
+
+    def listings(self, prob):
+        """(global index list, weight, param) per listing."""
+        g_idx = prob.N * prob.z + np.asarray(self.gcomps, dtype=np.int64)
+        if len(self.times1) == 0:
+            return [(g_idx, self.Qs[0], _param(self, 0))]
+        comps = np.asarray(self.comps, dtype=np.int64)
+        return [(np.concatenate([(t1 - 1) * prob.z + comps, g_idx]), self.Qs[i], _param(self, i))
+                for i, t1 in enumerate(self.times1)]
+
+
+@dataclass
 class ClosureKnotObjective:
     """KnotPointObjective / TerminalObjective with a user closure l(v, p)
     (src/objectives/knot_point_objectives.jl:65-243); analytic grad(v, p), hess(v, p) from the test."""
@@ -444,8 +487,14 @@ def _g_hess(con, v, mu, i=0):
     return mu[0] * 2.0 * np.eye(d)
 
 
+def _global_vals(con, prob, Z):
+    return Z[prob.N * prob.z + np.asarray(con.gcomps, dtype=np.int64)]
+
+
 def constraint_evaluate(con, prob, Z):
     """evaluate! -- knot_point_constraint.jl:235-247."""
+    if con.kind == "global_closure":  # global_constraint.jl:96-104
+        return np.asarray(con.g(_global_vals(con, prob, Z)), dtype=np.float64).reshape(con.g_dim)
     out = np.zeros(con.g_dim * len(con.times1))
     comps = np.asarray(con.comps)
     for i, t1 in enumerate(con.times1):
@@ -457,6 +506,13 @@ def constraint_evaluate(con, prob, Z):
 def constraint_jacobian(con, prob, Z):
     """eval_jacobian -- knot_point_constraint.jl:254-268 (exact zeros not stored)."""
     J = sp.lil_matrix((con.g_dim * len(con.times1), prob.n_vars))
+    if con.kind == "global_closure":  # global_constraint.jl:111-128
+        Jg = np.asarray(con.jac(_global_vals(con, prob, Z)), dtype=np.float64).reshape(con.g_dim, len(con.gcomps))
+        for r in range(con.g_dim):
+            for b, gc in enumerate(con.gcomps):
+                if Jg[r, b] != 0.0:
+                    J[r, prob.N * prob.z + gc] = Jg[r, b]
+        return J.tocsc()
     comps = np.asarray(con.comps)
     for i, t1 in enumerate(con.times1):
         v = _knot(Z, prob, t1 - 1)[comps]
@@ -471,6 +527,13 @@ def constraint_jacobian(con, prob, Z):
 def constraint_hessian(con, prob, Z, mu):
     """eval_hessian_of_lagrangian -- knot_point_constraint.jl:275-294."""
     H = sp.lil_matrix((prob.n_vars, prob.n_vars))
+    if con.kind == "global_closure":  # global_constraint.jl:141-158
+        Hg = np.asarray(con.hess(_global_vals(con, prob, Z), np.asarray(mu)), dtype=np.float64)
+        idx = prob.N * prob.z + np.asarray(con.gcomps, dtype=np.int64)
+        for a, ia in enumerate(idx):
+            for b, ib in enumerate(idx):
+                H[ia, ib] = Hg[a, b]
+        return H.tocsc()
     comps = np.asarray(con.comps)
     for i, t1 in enumerate(con.times1):
         v = _knot(Z, prob, t1 - 1)[comps]
@@ -496,6 +559,8 @@ def _baseline(term, t0):
 def term_value(term, prob, Z):
     """objective_value -- regularizers.jl:79-91, :240-249, minimum_time_objective.jl:44-50."""
     J = 0.0
+    if term.kind == "global_closure":  # global_objectives.jl:61-67, 218-235
+        return sum(Q * float(term.l(Z[idx], p)) for idx, Q, p in term.listings(prob))
     if term.kind == "knot_lowrank":
         return term_value(as_closure_objective(term), prob, Z)
     if term.kind == "knot_closure":  # knot_point_objectives.jl:173-182
@@ -528,6 +593,10 @@ def term_value(term, prob, Z):
 
 def term_gradient_accumulate(grad, term, prob, Z, scale=1.0):
     """gradient! (accumulating form) -- regularizers.jl:93-115, :251-271, minimum_time_objective.jl:52-66."""
+    if term.kind == "global_closure":  # global_objectives.jl:69-87, 237-275 (accumulating over the listings)
+        for idx, Q, p in term.listings(prob):
+            np.add.at(grad, idx, scale * Q * np.asarray(term.grad(Z[idx], p), dtype=np.float64))
+        return
     if term.kind == "knot_lowrank":
         return term_gradient_accumulate(grad, as_closure_objective(term), prob, Z, scale)
     if term.kind == "knot_closure":  # knot_point_objectives.jl:184-207 (per listed time: overwrite, then scale)
@@ -571,6 +640,12 @@ def term_hessian_structure(term, prob):
     S = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return S.tocsc()
+    if term.kind == "global_closure":  # global_objectives.jl:89-101, 277-300: the whole index block
+        for idx, _, _ in term.listings(prob):
+            for a in idx:
+                for b in idx:
+                    S[a, b] = 1.0
+        return S.tocsc()
     if term.kind in ("knot_sqdist", "knot_closure", "knot_lowrank"):  # knot_point_objectives.jl:209-222
         comps = np.asarray(term.comps)
         for t1 in term.times1:
@@ -599,6 +674,12 @@ def term_full_hessian(term, prob, Z):
     H = sp.lil_matrix((prob.n_vars, prob.n_vars))
     if term.kind == "mintime":
         return H.tocsc()
+    if term.kind == "global_closure":  # global_objectives.jl:104-125, 303-345 (`.+=` over the listings, full block)
+        Hd = np.zeros((prob.n_vars, prob.n_vars)) if prob.n_vars <= 4000 else None
+        for idx, Q, p in term.listings(prob):
+            Hl = Q * np.asarray(term.hess(Z[idx], p), dtype=np.float64).reshape(len(idx), len(idx))
+            Hd[np.ix_(idx, idx)] += Hl
+        return sp.csc_matrix(Hd)
     if term.kind == "knot_lowrank":
         return term_full_hessian(as_closure_objective(term), prob, Z)
     if term.kind == "knot_closure":  # hessian! per listed time (overwrite), triu (knot_point_objectives.jl:224-243)
@@ -931,6 +1012,61 @@ def make_external_integrator_problem(N=7, seed=9):
         return H
 
     prob.integrators = [prob.integrators[0], ClosureIntegrator(f, jac, hess, 2)] + prob.integrators[1:]
+    return prob
+
+
+def make_global_problem(N=7, seed=13, gd=3):
+    """Standard problem with global variables (traj.global_data, NamedTrajectories) and the three Global* kinds of the
+    reference: GlobalObjective Q l(g), GlobalKnotPointObjective sum_i Q_i l([x_t; g]) listed at repeated knots, and a
+    two-row NonlinearGlobalConstraint, the latter placed BETWEEN the knot constraints."""
+    prob = make_standard_problem(N=N, seed=seed)
+    rng = np.random.Generator(np.random.Philox(seed + 50))
+    prob.gd = gd
+    prob.Z0 = np.concatenate([prob.Z0, 0.5 + rng.random(gd)])
+
+    def lg(v, p):
+        return np.cosh(v[0]) + v[1] ** 2 * v[2]
+
+    def lg_grad(v, p):
+        return np.array([np.sinh(v[0]), 2.0 * v[1] * v[2], v[1] ** 2])
+
+    def lg_hess(v, p):
+        return np.array([[np.cosh(v[0]), 0.0, 0.0], [0.0, 2.0 * v[2], 2.0 * v[1]], [0.0, 2.0 * v[1], 0.0]])
+
+    # l([x1, u0, g2, g0], p) = g2 x1^2 + sin(u0 g0) + p0 g0
+    def lk(v, p):
+        return v[2] * v[0] ** 2 + np.sin(v[1] * v[3]) + p[0] * v[3]
+
+    def lk_grad(v, p):
+        c = np.cos(v[1] * v[3])
+        return np.array([2.0 * v[2] * v[0], v[3] * c, v[0] ** 2, v[1] * c + p[0]])
+
+    def lk_hess(v, p):
+        sn, c = np.sin(v[1] * v[3]), np.cos(v[1] * v[3])
+        H = np.zeros((4, 4))
+        H[0, 0] = 2.0 * v[2]
+        H[0, 2] = H[2, 0] = 2.0 * v[0]
+        H[1, 1] = -v[3] ** 2 * sn
+        H[1, 3] = H[3, 1] = c - v[1] * v[3] * sn
+        H[3, 3] = -v[1] ** 2 * sn
+        return H
+
+    def gc(v):
+        return np.array([v[0] * v[1] - 0.3, np.exp(v[1]) - 2.0])
+
+    def gc_jac(v):
+        return np.array([[v[1], v[0]], [0.0, np.exp(v[1])]])
+
+    def gc_hess(v, mu):
+        return mu[0] * np.array([[0.0, 1.0], [1.0, 0.0]]) + mu[1] * np.array([[0.0, 0.0], [0.0, np.exp(v[1])]])
+
+    kt = [2, 4, 4, N]
+    prob.objectives += [GlobalClosureObjective(lg, lg_grad, lg_hess, [], [0, 1, 2], [], [1.3]),
+                        GlobalClosureObjective(lk, lk_grad, lk_hess, [1, 4], [2, 0], kt, list(0.5 + rng.random(len(kt))),
+                                               params=[rng.standard_normal(1) for _ in kt])]
+    prob.weights = list(prob.weights) + [0.8, 1.1]
+    prob.constraints = [prob.constraints[0], GlobalClosureConstraint(gc, gc_jac, gc_hess, [2, 0], 2, equality=False),
+                        KnotConstraint("sqnorm", [6, 7], 0.5, [1, N - 1], equality=True)]
     return prob
 
 

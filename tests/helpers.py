@@ -21,7 +21,7 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
         else:
             ranges[(it.xdot_off, it.x_dim)] = None
     for t in prob.objectives:
-        if t.kind not in ("mintime", "knot_sqdist", "knot_closure", "knot_lowrank"):
+        if t.kind not in ("mintime", "knot_sqdist", "knot_closure", "knot_lowrank", "global_closure"):
             ranges[(t.comp_off, t.comp_dim)] = None
     ranges[(prob.dt_idx, 1)] = None
     cuts = sorted(ranges)
@@ -65,6 +65,19 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
             o.comps = np.asarray(t.comps, dtype=np.int32)
             o.Qs = np.asarray(t.Qs, dtype=np.float64)
             o.params = None if t.params is None else np.asarray(t.params, dtype=np.float64)
+        elif t.kind == "global_closure":
+            analytic = closure_derivatives == "analytic"
+            o = dto_amd.GlobalKnotPointObjective.__new__(dto_amd.GlobalKnotPointObjective)
+            o.l, o.grad, o.hess = t.l, (t.grad if analytic else None), (t.hess if analytic else None)
+            o.var_names, o.global_names = [], []
+            o.times = np.asarray(t.times1, dtype=np.int64)
+            o.comps = np.asarray(t.comps, dtype=np.int32)
+            o.gcomps = np.asarray(t.gcomps, dtype=np.int32)
+            o.Qs = np.asarray(t.Qs, dtype=np.float64)
+            nl = max(1, o.times.size)
+            o.params = [None] * nl if t.params is None else list(t.params)
+            if o.times.size == 0:  # GlobalObjective: the global variables alone
+                o._listings = (lambda Zk, g, o=o: [g[o.gcomps]])
         elif t.kind == "knot_lowrank":
             o = dto_amd.KnotPointObjective.__new__(dto_amd.KnotPointObjective)
             o.kind, o.var_names, o.external = "lowrank_infidelity", [], False
@@ -93,6 +106,15 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
     cons = []
     for c in prob.constraints:
         # component indices are passed through a synthetic single name when they form one range
+        if c.kind == "global_closure":
+            analytic = closure_derivatives == "analytic"
+            k = dto_amd.NonlinearGlobalConstraint.__new__(dto_amd.NonlinearGlobalConstraint)
+            k.g, k.jac, k.hess = c.g, (c.jac if analytic else None), (c.hess if analytic else None)
+            k.equality, k.global_names = bool(c.equality), []
+            k.gcomps = np.asarray(c.gcomps, dtype=np.int32)
+            k.global_dim, k.g_dim, k.dim = k.gcomps.size, c.g_dim, c.g_dim
+            cons.append(k)
+            continue
         k = dto_amd.NonlinearKnotPointConstraint.__new__(dto_amd.NonlinearKnotPointConstraint)
         if c.kind == "closure":
             analytic = closure_derivatives == "analytic"

@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol(engine_lib):
 def test_struct_sizes_match_header_layout():
     # sizes computed by hand from include/dto_engine.h (LP64): catches field drift between C and ctypes
     assert ctypes.sizeof(dto_amd.capi.IntegratorDesc) == 32
-    assert ctypes.sizeof(dto_amd.capi.ObjectiveDesc) == 96
-    assert ctypes.sizeof(dto_amd.capi.ConstraintDesc) == 56
+    assert ctypes.sizeof(dto_amd.capi.ObjectiveDesc) == 112
+    assert ctypes.sizeof(dto_amd.capi.ConstraintDesc) == 64
     assert ctypes.sizeof(dto_amd.capi.ProblemDesc) == 96
     assert ctypes.sizeof(dto_amd.capi.ShardInfo) == 112
     assert ctypes.sizeof(dto_amd.capi.ExternalValues) == 24
@@ -99,6 +99,7 @@ PROBLEMS = {
     "closure": lambda: O.make_closure_problem(),
     "ket": lambda: O.make_ket_problem(),
     "external_integrator": lambda: O.make_external_integrator_problem(),
+    "global": lambda: O.make_global_problem(),
 }
 
 

@@ -237,3 +237,52 @@ def test_time_dependent_bilinear_through_the_merge_path():
         assert np.isfinite(H).all()
     finally:
         ev.close()
+
+
+def test_global_terms_merged_from_host_blocks():
+    """SURVEY.md §8f rank 2, Global* kinds: GlobalObjective, GlobalKnotPointObjective (repeated knots: blocks accumulate)
+    and a NonlinearGlobalConstraint between knot constraints; their Hessian entries in the global-variable columns
+    form the tail of the CSC order, the constraint's Jacobian entries sit in the global columns."""
+    p = O.make_global_problem()
+    _check(p, tag="global/analytic", closure_derivatives="analytic")
+    Z = p.Z0 + 0.05 * np.random.default_rng(8).standard_normal(p.n_vars)
+    _check(p, Z=Z, tag="global/numeric", closure_derivatives="numeric", tol_h=1e-6)
+
+
+def test_global_terms_sharded():
+    import dto_amd
+    p = O.make_global_problem(N=9)
+    ev_o = O.OracleEvaluator(p)
+    Z = p.Z0 + 0.02 * np.random.default_rng(5).standard_normal(p.n_vars)
+    mu = np.random.default_rng(6).standard_normal(ev_o.n_constraints)
+    ev = dto_amd.Evaluator(to_engine(p, "analytic"))  # J w / J' w reach the global-variable columns too
+    try:
+        w = np.random.default_rng(7).standard_normal(p.n_vars)
+        y = np.empty(ev_o.n_constraints); ev.eval_constraint_jacobian_product(y, Z, w)
+        assert rel_err(y, ev_o.eval_constraint_jacobian_product(Z, w)) <= 1e-10
+        w = np.random.default_rng(8).standard_normal(ev_o.n_constraints)
+        y = np.empty(p.n_vars); ev.eval_constraint_jacobian_transpose_product(y, Z, w)
+        assert rel_err(y, ev_o.eval_constraint_jacobian_transpose_product(Z, w)) <= 1e-10
+    finally:
+        ev.close()
+    ref = {"jac": ev_o.eval_constraint_jacobian(Z), "hess": ev_o.eval_hessian_lagrangian(Z, 0.3, mu),
+           "grad": ev_o.eval_objective_gradient(Z), "cons": ev_o.eval_constraint(Z)}
+    got = {k: np.full_like(v, np.nan) for k, v in ref.items()}
+    f = 0.0
+    for lo, hi in dto_amd.distributed.shard_ranges(p.N, 3):
+        ev = dto_amd.Evaluator(to_engine(p, "analytic"), k_lo=lo, k_hi=hi)
+        s = ev.shard
+        f += ev.eval_objective(Z)
+        o = np.empty(s.grad_len); ev.eval_objective_gradient(o, Z); got["grad"][s.grad_lo:s.grad_lo + s.grad_len] = o
+        o = np.empty(s.jac_len); ev.eval_constraint_jacobian(o, Z); got["jac"][s.jac_lo:s.jac_lo + s.jac_len] = o
+        o = np.empty(s.hess_len); ev.eval_hessian_lagrangian(o, Z, 0.3, mu); got["hess"][s.hess_lo:s.hess_lo + s.hess_len] = o
+        o = np.empty(s.cons_len); ev.eval_constraint(o, Z)
+        st, ln = ev.shard_rows()
+        pos = 0
+        for a, b in zip(st, ln):
+            got["cons"][a - 1:a - 1 + b] = o[pos:pos + b]
+            pos += b
+        ev.close()
+    assert rel_err(f, ev_o.eval_objective(Z)) <= 1e-12
+    for k in ref:
+        assert rel_err(got[k], ref[k]) <= (1e-8 if k == "hess" else 1e-10), k
