@@ -1025,6 +1025,9 @@ void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int trans
     launch_sweep_kernel(st, a, 1);
 }
 
+// (Running this test inside the step kernel -- last workgroup per column block, found by an atomic counter -- was
+// measured 2x SLOWER per step: the agent-scope release fence each workgroup needs before bumping the counter writes the
+// XCD's L2 back (the eight L2s are not coherent with each other), which a kernel boundary does once for everybody.)
 // Termination test of the Taylor recurrences (Al-Mohy & Higham 2011, Alg. 3.2 line 13 form):
 // a block of TN intervals stops when, for every column of every type, two successive terms are
 // below tol * |sum|.  Also recycles the term-norm slot the next step will write.
