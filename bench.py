@@ -61,6 +61,33 @@ def cpu_baseline(n, m, N, budget_s=20.0):
                       f"{knots} of the {N - 1} intervals of the same problem, {dt:.1f} s"}
 
 
+def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
+    out = {}
+    ev = dto_amd.Evaluator(prob, eval_hessian=True, device=dev.index)
+    try:
+        mu = torch.ones(ev.n_constraints, dtype=torch.float64, device=dev)
+        bufs = {"eval_hessian_lagrangian": torch.empty(ev.shard.hess_len, dtype=torch.float64, device=dev),
+                "eval_constraint": torch.empty(ev.shard.cons_len, dtype=torch.float64, device=dev),
+                "eval_objective_gradient": torch.empty(ev.shard.grad_len, dtype=torch.float64, device=dev)}
+        calls = {"eval_hessian_lagrangian": lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), bufs["eval_hessian_lagrangian"].data_ptr(), stream),
+                 "eval_constraint": lambda: ev.eval_constraint_dev(Z.data_ptr(), bufs["eval_constraint"].data_ptr(), stream),
+                 "eval_objective_gradient": lambda: ev.eval_gradient_dev(Z.data_ptr(), bufs["eval_objective_gradient"].data_ptr(), stream)}
+        for name, fn in calls.items():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / 5
+            out[name] = {"ms_per_call": dt * 1e3, "knot_points_per_s": N / dt,
+                         "finite": bool(torch.isfinite(bufs[name]).all().item())}
+    finally:
+        ev.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +98,7 @@ def main():
     ap.add_argument("--knots", type=int, default=2000, help="knots per GPU")
     ap.add_argument("--callback", default="jacobian", choices=["jacobian", "hessian", "constraint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-callbacks", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -198,6 +226,10 @@ def main():
                                  "ms_per_step": ms_sweep / args.steps, "launches": n_sweep,
                                  "achieved_tflops": fl_sweep / (ms_sweep * 1e-3) / 1e12 if ms_sweep > 0 else 0.0},
         }
+        if world == 1 and args.callback == "jacobian" and not args.no_other_callbacks:
+            # the other callbacks of the same problem, same protocol (3 untimed + 5 timed calls each): reported for
+            # context (SURVEY.md §8d lists them next to the headline), never part of `value`
+            line["other_callbacks"] = other_callbacks(dto_amd, torch, prob, ev, dev, Z, stream, N_total)
         if world == 1 and not args.no_cpu_baseline and args.callback == "jacobian":
             try:
                 line["cpu_baseline"] = cpu_baseline(n, m, Nk, args.cpu_budget)

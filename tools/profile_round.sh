@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-other-callbacks"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- $B --steps 5 --warmup 2 > $O/prof_$tag.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- $B --steps 2 --warmup 1 > $O/pmc_fetch_$tag.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- $B --steps 2 --warmup 1 > $O/pmc_write_$tag.log 2>&1
