@@ -21,6 +21,11 @@ CASES = {
     "scaled_n8_m2_N6": lambda: O.make_scaled_problem(6, 8, 2, seed=14, with_constraint=True),
     "scaled_n16_m4_N5": lambda: O.make_scaled_problem(5, 16, 4, seed=21, with_constraint=True),
     "skew_n32_m2_N4": lambda: O.make_scaled_problem(4, 32, 2, seed=5, skew=True),
+    # host-evaluated / merged term kinds and the built-in coherent-fidelity loss
+    "ket_infidelity_N8": lambda: O.make_ket_problem(),
+    "closure_terms_N9": lambda: O.make_closure_problem(),
+    "external_integrator_N7": lambda: O.make_external_integrator_problem(),
+    "global_terms_N7": lambda: O.make_global_problem(),
 }
 
 

@@ -27,7 +27,7 @@ CASES = _cases()
 def test_engine_matches_golden(name):
     import dto_amd
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    ev = dto_amd.Evaluator(to_engine(CASES[name]()))
+    ev = dto_amd.Evaluator(to_engine(CASES[name](), "analytic"))
     try:
         r, c = ev.jacobian_structure()
         assert np.array_equal(r, g["jac_rows"]) and np.array_equal(c, g["jac_cols"])
