@@ -66,7 +66,7 @@ struct BilHost {
     double* d_n2 = nullptr;
     ChainWork chain{};
     int chain_cap = 0;
-    bool small = false;       // n <= 16: fused one-wavefront-per-interval path (dto_small.hip)
+    bool small = false;       // n <= 32: fused one-workgroup-per-interval path (dto_small.hip)
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
     BasisSet basis[3]{};      // degrees 2, 3, 4
@@ -999,7 +999,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                     b.k.G = own(h, dupload(G));
                     b.k.GT = own(h, dupload(GT));
                     static const bool small_on = [] { const char* e = getenv("DTO_SMALL_N"); return !e || atoi(e) != 0; }();
-                    if (small_on && n <= 16) {
+                    // fused one-workgroup-per-interval path: n <= 16 with one wavefront, 17..32 with four, while the
+                    // interval's matrices, generators and sweep columns fit the CU's LDS
+                    const int mm_ = s.u_dim, Tf = d->eval_hessian ? 1 + mm_ + mm_ * (mm_ + 1) / 2 : 1 + mm_;
+                    if (small_on && n <= 32 && Tf <= MAX_TYPES && small_lds_bytes(n, mm_, Tf, 1 + mm_) <= 150 * 1024) {
                         b.small = true;
                         b.d_Gs = own(h, dupload(std::vector<double>(s.G, s.G + (size_t)m1 * n * n)));
                     }

@@ -251,6 +251,7 @@ void launch_fill(hipStream_t st, double* p, int64_t n, double v);
 
 // Small-state path (dto_small.hip): one wavefront per interval, everything in LDS.  mode bits: 1 constraint
 // values, 2 Jacobian block, 4 Hessian block.  Gs = compact (m+1) x n x n generators.
+size_t small_lds_bytes(int n, int m, int T_fw, int T_ad);
 void launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* Gs, const SweepTypes& ty_fw,
                   const SweepTypes& ty_ad, const double* dZ, const double* dmu, double* cons, double* jac, double* hess,
                   int mode);

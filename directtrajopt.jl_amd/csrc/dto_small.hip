@@ -1,4 +1,5 @@
-// dto_small.hip -- small-state path (n <= 16): ONE WAVEFRONT PER KNOT INTERVAL, everything in LDS.
+// dto_small.hip -- small-state path (n <= 32): ONE WORKGROUP PER KNOT INTERVAL (one wavefront for n <= 16, four for
+// 17..32), everything in LDS.
 //
 // This is the shape the reference's own benchmarks have (4..16 states, N ~ 50..100,
 // benchmark/problem_utils.jl:10-42, docs/src/benchmarks.md:83-124): the work per interval is a few
@@ -11,6 +12,7 @@
 // with the same mathematics as the large path: Taylor degree 16 + squarings for E_k (Horner form: n is
 // tiny, products are free), Taylor recurrences with Al-Mohy--Higham termination for the vector quantities.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "dto_kernels.h"
 
@@ -31,9 +33,10 @@ __device__ __forceinline__ double wsum(double v) {
     return v;
 }
 
-// C = A * B (n x n, column-major, LDS), all 64 lanes
+// C = A * B (n x n, column-major, LDS), all NT threads
+template <int NT>
 __device__ __forceinline__ void mm(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B, int n) {
-    for (int e = threadIdx.x; e < n * n; e += 64) {
+    for (int e = threadIdx.x; e < n * n; e += NT) {
         const int r = e % n, c = e / n;
         double s = 0.0;
         for (int k = 0; k < n; ++k) s += A[r + k * n] * B[k + c * n];
@@ -59,12 +62,13 @@ struct SmallLds {
 
 // Taylor recurrences for T column types starting from term0 (type 0 = v0, others 0); sums left in S.
 //   transposed = 0: A v, G_g v      1: A' v, G_g' v
+template <int NT>
 __device__ void small_sweep(const SmallLds& L, const SweepTypes& ty, int n, int m, const double* ub, double dt,
                             const double* v0, double* S, int transposed, double beta) {
     const int T = ty.T;
     const int q = beta == beta && beta < 1e6 ? max(1, (int)ceil(beta / 9.0)) : 1;
     const double dq = dt / q;
-    for (int e = threadIdx.x; e < T * n; e += 64) {
+    for (int e = threadIdx.x; e < T * n; e += NT) {
         const double v = e < n ? v0[e] : 0.0;
         L.cur[e] = v;
         S[e] = v;
@@ -72,14 +76,14 @@ __device__ void small_sweep(const SmallLds& L, const SweepTypes& ty, int n, int 
     __syncthreads();
     for (int round = 0; round < q; ++round) {
         if (round > 0) {
-            for (int e = threadIdx.x; e < T * n; e += 64) L.cur[e] = S[e];
+            for (int e = threadIdx.x; e < T * n; e += NT) L.cur[e] = S[e];
             __syncthreads();
         }
         for (int t = 0; t < SMALL_MAX_TERMS; ++t) {
             const double inv = 1.0 / (double)(t + 1);
             if (threadIdx.x < T) { L.tn[threadIdx.x] = 0ull; L.sn[threadIdx.x] = 0ull; }
             __syncthreads();
-            for (int e = threadIdx.x; e < T * n; e += 64) {
+            for (int e = threadIdx.x; e < T * n; e += NT) {
                 const int tau = e / n, i = e % n;
                 const double* c = L.cur + tau * n;
                 double acc = 0.0;
@@ -110,8 +114,8 @@ __device__ void small_sweep(const SmallLds& L, const SweepTypes& ty, int n, int 
                 ok = (pv + tnv <= 1.1e-16 * snv) || !(tnv == tnv) || !(snv < 1e300);
                 L.pn[threadIdx.x] = tnv;
             }
-            const bool done = __all(ok);
-            for (int e = threadIdx.x; e < T * n; e += 64) L.cur[e] = L.nxt[e];
+            const bool done = __syncthreads_and(ok);
+            for (int e = threadIdx.x; e < T * n; e += NT) L.cur[e] = L.nxt[e];
             __syncthreads();
             if (done) break;
         }
@@ -133,7 +137,8 @@ struct SmallArgs {
     int mode;           // bit0 constraint values, bit1 Jacobian, bit2 Hessian
 };
 
-__global__ void __launch_bounds__(64) k_small(SmallArgs a) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_small(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KProb& P = a.P;
     const KBil& B = a.B;
@@ -164,10 +169,10 @@ __global__ void __launch_bounds__(64) k_small(SmallArgs a) {
     ub[0] = 1.0;
     for (int j = 0; j < m; ++j) ub[j + 1] = zk[B.u_off + j];
 
-    for (int e = threadIdx.x; e < (m + 1) * nn; e += 64) L.G[e] = a.Gs[e];
+    for (int e = threadIdx.x; e < (m + 1) * nn; e += NT) L.G[e] = a.Gs[e];
     __syncthreads();
     double colsum = 0.0;
-    for (int e = threadIdx.x; e < nn; e += 64) {
+    for (int e = threadIdx.x; e < nn; e += NT) {
         double s = 0.0;
         for (int j = 0; j <= m; ++j) s += ub[j] * L.G[j * nn + e];
         L.A[e] = dt * s;
@@ -175,22 +180,30 @@ __global__ void __launch_bounds__(64) k_small(SmallArgs a) {
     __syncthreads();
     // ||A||_1 (exact): drives both the scaling of the matrix exponential and the sub-stepping of the sweeps
     double n1 = 0.0;
-    for (int c = threadIdx.x; c < n; c += 64) {
+    for (int c = threadIdx.x; c < n; c += NT) {
         double s = 0.0;
         for (int r = 0; r < n; ++r) s += fabs(L.A[r + c * n]);
         n1 = fmax(n1, s);
     }
     n1 = wmax(n1);
+    if (NT > 64) {  // several wavefronts: combine through LDS (the slot is rewritten by the sweep afterwards)
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) L.pn[threadIdx.x >> 6] = n1;
+        __syncthreads();
+        n1 = L.pn[0];
+        for (int w = 1; w < NT / 64; ++w) n1 = fmax(n1, L.pn[w]);
+        __syncthreads();
+    }
     if (!(n1 == n1)) n1 = __longlong_as_double(0x7ff8000000000000ll);
     (void)colsum;
 
     const double* xk = zk + B.x_off;
     double* yv = L.S;  // forward sums: S[0] = exp(A) x, S[1+j] = dexp(A)[dt G_j] x, then h^{ij}
-    small_sweep(L, a.ty_fw, n, m, ub, dt, xk, L.S, 0, n1);
+    small_sweep<NT>(L, a.ty_fw, n, m, ub, dt, xk, L.S, 0, n1);
     __syncthreads();
     // GY = G(u) y
     double* GY = L.vec;
-    for (int i = threadIdx.x; i < n; i += 64) {
+    for (int i = threadIdx.x; i < n; i += NT) {
         double s = 0.0;
         for (int j = 0; j <= m; ++j) {
             double g = 0.0;
@@ -202,7 +215,7 @@ __global__ void __launch_bounds__(64) k_small(SmallArgs a) {
     __syncthreads();
 
     if (a.mode & 1) {
-        for (int r = threadIdx.x; r < n; r += 64)
+        for (int r = threadIdx.x; r < n; r += NT)
             a.cons[B.lrow_off + kl * n + r] = a.Z[(kn + 1) * P.z + B.x_off + r] - yv[r];
     }
 
@@ -212,49 +225,49 @@ __global__ void __launch_bounds__(64) k_small(SmallArgs a) {
         if (n1 > THETA_16) s = (int)ceil(log2(n1 / THETA_16));
         if (!(n1 == n1) || s > 60) s = 60;
         const double sigma = ldexp(1.0, -s);
-        for (int e = threadIdx.x; e < nn; e += 64) L.X[e] = (e % n == e / n) ? 1.0 : 0.0;
+        for (int e = threadIdx.x; e < nn; e += NT) L.X[e] = (e % n == e / n) ? 1.0 : 0.0;
         __syncthreads();
         for (int i = TAYLOR_M; i >= 1; --i) {
-            mm(L.Y, L.A, L.X, n);
+            mm<NT>(L.Y, L.A, L.X, n);
             __syncthreads();
             const double f = sigma / (double)i;
-            for (int e = threadIdx.x; e < nn; e += 64) L.X[e] = ((e % n == e / n) ? 1.0 : 0.0) + f * L.Y[e];
+            for (int e = threadIdx.x; e < nn; e += NT) L.X[e] = ((e % n == e / n) ? 1.0 : 0.0) + f * L.Y[e];
             __syncthreads();
         }
         for (int it = 0; it < s; ++it) {
-            mm(L.Y, L.X, L.X, n);
+            mm<NT>(L.Y, L.X, L.X, n);
             __syncthreads();
-            for (int e = threadIdx.x; e < nn; e += 64) L.X[e] = L.Y[e];
+            for (int e = threadIdx.x; e < nn; e += NT) L.X[e] = L.Y[e];
             __syncthreads();
         }
         // Jacobian block of interval kn (own rows): x columns = -E, u_j = -c_j, dt = -G(u) y
-        for (int e = threadIdx.x; e < nn; e += 64) {
+        for (int e = threadIdx.x; e < nn; e += NT) {
             const int r = e % n, c = e / n;
             a.jac[jac_pos(P, P.colptr, kn, B.x_off + c, B.pre, n, 1, r)] = -L.X[e];
         }
-        for (int e = threadIdx.x; e < m * n; e += 64) {
+        for (int e = threadIdx.x; e < m * n; e += NT) {
             const int j = e / n, r = e % n;
             a.jac[jac_pos(P, P.colptr, kn, B.u_off + j, B.pre, n, 1, r)] = -L.S[(1 + j) * n + r];
         }
-        for (int r = threadIdx.x; r < n; r += 64) a.jac[jac_pos(P, P.colptr, kn, P.dt_idx, B.pre, n, 1, r)] = -GY[r];
+        for (int r = threadIdx.x; r < n; r += NT) a.jac[jac_pos(P, P.colptr, kn, P.dt_idx, B.pre, n, 1, r)] = -GY[r];
     }
 
     if (a.mode & 4) {
         const double* muk = a.mu + B.row_off + kn * n;
         double* muv = L.vec + 3 * n;
-        for (int i = threadIdx.x; i < n; i += 64) muv[i] = muk[i];
+        for (int i = threadIdx.x; i < n; i += NT) muv[i] = muk[i];
         __syncthreads();
-        small_sweep(L, a.ty_ad, n, m, ub, dt, muv, L.S2, 1, n1);
+        small_sweep<NT>(L, a.ty_ad, n, m, ub, dt, muv, L.S2, 1, n1);
         __syncthreads();
         double* GYt = L.vec + n;   // G(u)' yt
         double* Gm = L.vec + 2 * n;  // G(u)' mu
-        for (int e = threadIdx.x; e < (m + 1) * n; e += 64) {
+        for (int e = threadIdx.x; e < (m + 1) * n; e += NT) {
             const int j = e / n, i = e % n;
             double g = 0.0;
             for (int k = 0; k < n; ++k) g += L.G[j * nn + k + i * n] * muv[k];
             L.W[e] = g;
         }
-        for (int i = threadIdx.x; i < n; i += 64) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             double s = 0.0;
             for (int j = 0; j <= m; ++j) {
                 double g = 0.0;
@@ -264,7 +277,7 @@ __global__ void __launch_bounds__(64) k_small(SmallArgs a) {
             GYt[i] = s;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 64) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             double s = 0.0;
             for (int j = 0; j <= m; ++j) s += ub[j] * L.W[j * n + i];
             Gm[i] = s;
@@ -274,14 +287,14 @@ __global__ void __launch_bounds__(64) k_small(SmallArgs a) {
             const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
             atomicAdd(&a.hess[hess_pos(P, kn, lo, hi)], v);
         };
-        for (int e = threadIdx.x; e < m * n; e += 64) {
+        for (int e = threadIdx.x; e < m * n; e += NT) {
             const int j = e / n, r = e % n;
             hadd(B.x_off + r, B.u_off + j, -L.S2[(1 + j) * n + r]);
         }
-        for (int r = threadIdx.x; r < n; r += 64) hadd(B.x_off + r, P.dt_idx, -GYt[r]);
+        for (int r = threadIdx.x; r < n; r += NT) hadd(B.x_off + r, P.dt_idx, -GYt[r]);
         // scalar blocks: one lane per entry
         const int npair = m * (m + 1) / 2;
-        for (int e = threadIdx.x; e < npair + m + 1; e += 64) {
+        for (int e = threadIdx.x; e < npair + m + 1; e += NT) {
             if (e < npair) {
                 int i = 0, rem = e;
                 while (rem >= m - i) { rem -= m - i; ++i; }
@@ -323,11 +336,32 @@ void launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* G
     SmallArgs a{};
     a.P = P; a.B = B; a.ty_fw = ty_fw; a.ty_ad = ty_ad; a.Gs = Gs; a.Z = dZ; a.mu = dmu;
     a.cons = cons; a.jac = jac; a.hess = hess; a.mode = mode;
-    const int n = B.n, m = B.m, nn = n * n;
-    const int Tmax = ty_fw.T > ty_ad.T ? ty_fw.T : ty_ad.T;
-    const size_t doubles = (size_t)(m + 1) * nn + 3 * nn + 2 * Tmax * n + (size_t)ty_fw.T * n + (size_t)ty_ad.T * n +
-                           (size_t)(m + 1) * n + 4 * n + 3 * MAX_TYPES;
-    hipLaunchKernelGGL(k_small, dim3((unsigned)P.n_int), dim3(64), doubles * sizeof(double), st, a);
+    const int n = B.n, m = B.m;
+    const size_t bytes = small_lds_bytes(n, m, ty_fw.T, ty_ad.T);
+    // n <= 16: one wavefront per interval; 17..32: four (the n^3 products of the matrix exponential dominate there).
+    // (A variant for 33..64 -- MFMA products on zero-padded matrices, generators left in global memory -- was correct
+    // but slower than the general path at N = 1000: one 130 KB workgroup per CU and scalar sweeps; dropped.)
+    if (n <= 16) {
+        hipLaunchKernelGGL(k_small<64>, dim3((unsigned)P.n_int), dim3(64), bytes, st, a);
+    } else {
+        static size_t have = 0;  // dynamic LDS beyond 64 KB has to be opted into, per kernel
+        if (bytes > have) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small<256>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) fprintf(stderr, "dto: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed: %s\n", bytes, hipGetErrorString(e));
+            else have = bytes;
+        }
+        hipLaunchKernelGGL(k_small<256>, dim3((unsigned)P.n_int), dim3(256), bytes, st, a);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "dto: fused-interval kernel launch failed (n=%d, %zu B LDS): %s\n", n, bytes, hipGetErrorString(e));
+}
+
+// LDS bytes the fused kernel needs for one interval (the engine falls back to the general path beyond the CU's 160 KB)
+size_t small_lds_bytes(int n, int m, int T_fw, int T_ad) {
+    const int nn = n * n, Tmax = T_fw > T_ad ? T_fw : T_ad;
+    return ((size_t)(m + 1) * nn + 3 * nn + 2 * Tmax * n + (size_t)T_fw * n + (size_t)T_ad * n + (size_t)(m + 1) * n + 4 * n +
+            3 * MAX_TYPES) * sizeof(double);
 }
 
 }  // namespace dto

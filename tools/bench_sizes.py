@@ -22,6 +22,11 @@ def run(n, m, N, cb="jacobian", steps=3):
     ev.close()
 for cb in ("constraint","jacobian","hessian"):
     run(64, 4, 1000, cb)
-for cb in ("constraint","jacobian","hessian"):
-    run(1024, 4, 500, cb, steps=2)  # configs[4] per-GPU share: N=4000 over 8 GPUs
+if "--big" in sys.argv:
+    for cb in ("constraint","jacobian","hessian"):
+        run(1024, 4, 500, cb, steps=2)  # configs[4] per-GPU share: N=4000 over 8 GPUs
 run(4, 2, 51, "jacobian"); run(4, 2, 51, "hessian")
+for cb in ("constraint","jacobian","hessian"):
+    run(32, 4, 100, cb, steps=5)
+for cb in ("constraint","jacobian","hessian"):
+    run(17, 3, 1000, cb, steps=5)
