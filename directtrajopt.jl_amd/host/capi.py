@@ -93,7 +93,9 @@ SYMBOLS = {
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libdto_engine.so")
+    """In-tree engine library; DTO_ENGINE_LIB names another build of it (A/B runs of kernel variants)."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.path.join(here, os.environ.get("DTO_ENGINE_LIB", "libdto_engine.so"))
 
 
 _lib = None
