@@ -66,6 +66,10 @@ struct BilHost {
     double* d_n2 = nullptr;
     ChainWork chain{};
     int chain_cap = 0;
+    unsigned long long* d_hump = nullptr;  // [8] k_hump output: log hump(q), last term index, q = 1..4 (max over intervals)
+    double hump_logH[4] = {0, 0, 0, 0};
+    int hump_kend[4] = {0, 0, 0, 0};
+    bool hump_valid = false;
     bool small = false;       // n <= 32: fused one-workgroup-per-interval path (dto_small.hip)
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
@@ -162,7 +166,7 @@ struct dto_handle {
     double* d_w = nullptr;               // product input
     int64_t* d_conbase = nullptr;        // [n_vars+1] first constraint-pattern entry of each column
     int64_t* d_con_rows = nullptr;       // constraint-pattern rows, (col,row) order
-    double* h_pinned = nullptr;  // [4]
+    double* h_pinned = nullptr;  // [32]: 0-1 bounds, 2-3 chain scalars, 6 sweep stats, 16-23 hump readback
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr;
@@ -407,6 +411,8 @@ Bounds get_bounds(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
 struct SweepPlan {
     int q, d_ub;
 };
+void read_hump(dto_handle* h, BilHost& b);
+SweepPlan plan_hump(const BilHost& b, double beta_fallback);
 
 SweepPlan plan_sweep(double beta) {
     SweepPlan p{1, 12};
@@ -414,7 +420,7 @@ SweepPlan plan_sweep(double beta) {
         p.q = 1; p.d_ub = 30;
         return p;
     }
-    const double theta_v = 9.0;  // worst-case cancellation budget e^9 ~ 1e4 on the Taylor sums (tolerance 1e-10)
+    static const double theta_v = [] { const char* e = getenv("DTO_THETA_V"); return e ? atof(e) : 9.0; }();  // worst-case cancellation budget e^9 ~ 1e4 on the Taylor sums (tolerance 1e-10)
     p.q = std::max(1, (int)std::ceil(beta / theta_v));
     const double br = beta / p.q;
     int t = 8;
@@ -569,6 +575,7 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     for (int i = 0; i < 6; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
     b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
     b.chain.colsum = own(h, dalloc<double>((size_t)3 * cap * b.k.npad));
+    if (!b.d_hump) b.d_hump = own(h, dalloc<unsigned long long>(8));
     b.chain.coef = own(h, dalloc<double>((size_t)cap * COEF_STRIDE));
     b.chain.s = own(h, dalloc<int32_t>(cap));
     b.chain.smax = own(h, dalloc<int32_t>(4));
@@ -632,10 +639,13 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         if (!b.use_basis) launch_norm1(st, npad, nb, w);
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
         launch_expm_params(st, nb, s_ub, w);
+        if (c0 == 0) HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
+        launch_hump(st, h->P, b.k, dZ, b.d_g1, int0, nb, w.norms, b.d_hump);
         // the number of squaring launches is data dependent: read back max/sum of s_k (8 bytes) while
         // the Horner products run
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
         HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         hipEvent_t ev_s;
         HIP_CHECK(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(ev_s, st));
@@ -653,6 +663,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         HIP_CHECK(hipEventSynchronize(ev_s));
         HIP_CHECK(hipEventDestroy(ev_s));
         const int s_max = hs[0];
+        read_hump(h, b);  // accumulated over the chunks so far; final after the last one
         {
             double dv;
             memcpy(&dv, hs + 2, sizeof(double));
@@ -685,6 +696,8 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, boo
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
+        launch_fill(st, w.norms, (int64_t)nb * 4, INFINITY);  // norms not computed below stay "unknown" for k_hump
+        if (c0 == 0) HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
         if (b.use_basis) {
             // ||A_k^2||_1 straight from the generator-subspace GEMM's fused column sums: neither A nor A^2 is
             // written (K = number of degree-2 products: a few GFLOP for all intervals)
@@ -703,22 +716,48 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, boo
             launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]);
             launch_norm1_one(st, npad, nb, w, 1);
         }
+        launch_hump(st, h->P, b.k, dZ, b.d_g1, int0, nb, w.norms, b.d_hump);
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
         HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         double dv;
         memcpy(&dv, hs + 2, sizeof(double));
         d2max = (dv == dv) ? std::max(d2max, dv) : dv;
     }
+    read_hump(h, b);
     return d2max;
+}
+
+// Plan from the a-priori hump bound of k_hump: the fewest rounds whose Taylor sums cannot lose more than theta_v
+// e-folds to cancellation; falls back to the growth-rate rule when no q <= 4 qualifies or the bound is not finite.
+void read_hump(dto_handle* h, BilHost& b) {
+    const unsigned long long* hp = reinterpret_cast<const unsigned long long*>(h->h_pinned + 16);
+    b.hump_valid = true;
+    for (int q = 0; q < 4; ++q) {
+        double v;
+        memcpy(&v, &hp[q], sizeof(double));
+        b.hump_logH[q] = v;
+        b.hump_kend[q] = (int)hp[4 + q];
+        if (!(v == v)) b.hump_valid = false;
+    }
+}
+SweepPlan plan_hump(const BilHost& b, double beta_fallback) {
+    static const double theta_v = [] { const char* e = getenv("DTO_THETA_V"); return e ? atof(e) : 9.0; }();
+    static const bool on = [] { const char* e = getenv("DTO_HUMP_PLAN"); return !e || atoi(e) != 0; }();
+    if (on && b.hump_valid)
+        for (int q = 1; q <= 4; ++q)
+            if (b.hump_logH[q - 1] <= theta_v) return SweepPlan{q, std::min(200, b.hump_kend[q - 1] + 6)};
+    return plan_sweep(beta_fallback);
 }
 
 SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
     Bounds bd = get_bounds(h, b, dZ, st);
     if (plan_sweep(bd.beta).q == 1) return plan_sweep(bd.beta);  // the cheap bound already gives one round
     double d2 = exact_d2(h, b, dZ, st);
-    if (d2 == d2 && plan_sweep(std::min(bd.beta, d2)).q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);
-    return plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
+    auto plan = [&] { return plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2); };
+    if (d2 == d2 && plan().q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);  // ||A^3||, ||A^4|| sharpen the bound
+    return plan();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -797,7 +836,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
             run_chain(h, b, dZ, dvals, bd.b1, st, [&](double d2) {
                 // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
                 // (and still rigorous) growth rate for the sweep's step budget
-                SweepPlan plan = plan_sweep(d2 == d2 ? std::min(bd.beta, d2) : d2);
+                SweepPlan plan = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);
                 SweepTypes ty = make_types(b.k.m, false);
                 run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss);
                 launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
@@ -1347,7 +1386,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         h->d_partial = own(h, dalloc<double>(256));
         h->d_f = own(h, dalloc<double>(1));
         h->d_bounds = own(h, dalloc<double>(2));
-        HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 8 * sizeof(double)));
+        HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 32 * sizeof(double)));
 
         // per-bilinear workspaces + generator product norms (for the step-budget bounds)
         for (auto& b : h->bil) {

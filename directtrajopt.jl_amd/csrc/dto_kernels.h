@@ -286,6 +286,8 @@ void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals
 void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum);
 // norms[b*4 + which] = max_c colsum[b][c]
 void launch_beta_from_norms(hipStream_t st, int nb, const ChainWork& w);
+void launch_hump(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, const double* g1, int64_t int0, int nb,
+                 const double* norms, unsigned long long* out);
 void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* colsum, double* norms, int which,
                              unsigned long long* d2max = nullptr);
 // out2[0] = max_k min(b1_k, b2_k), out2[1] = max_k b1_k (bit patterns of non-negative doubles), where
