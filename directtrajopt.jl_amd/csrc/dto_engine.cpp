@@ -169,7 +169,7 @@ struct dto_handle {
     double* h_pinned = nullptr;  // [32]: 0-1 bounds, 2-3 chain scalars, 6 sweep stats, 16-23 hump readback
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr, ev_chain = nullptr;
 
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -195,6 +195,7 @@ dto_handle::~dto_handle() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_stats) (void)hipEventDestroy(ev_stats);
+    if (ev_chain) (void)hipEventDestroy(ev_chain);
 }
 
 namespace {
@@ -646,8 +647,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
         HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        hipEvent_t ev_s;
-        HIP_CHECK(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
+        hipEvent_t ev_s = h->ev_chain;
         HIP_CHECK(hipEventRecord(ev_s, st));
         if (b.use_basis) {
             const int nbpad = ((nb + 127) / 128) * 128;
@@ -661,7 +661,6 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
         { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
         HIP_CHECK(hipEventSynchronize(ev_s));
-        HIP_CHECK(hipEventDestroy(ev_s));
         const int s_max = hs[0];
         read_hump(h, b);  // accumulated over the chunks so far; final after the last one
         {
@@ -995,6 +994,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;
