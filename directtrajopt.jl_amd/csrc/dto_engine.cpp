@@ -1449,8 +1449,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 long cnt = 0;
                 long c2 = (long)m1 * (m1 + 1) / 2, c3 = c2 * (m1 + 2) / 3, c4 = c3 * (m1 + 3) / 4;
                 cnt = c2 + c3 + c4;
-                bool want = npad % 128 == 0 && cnt * 2 <= 3L * npad;
-                if (const char* e = getenv("DTO_BASIS_POWERS")) want = atoi(e) != 0 && npad % 128 == 0;
+                // (npad is a multiple of 64: npad^2 is a multiple of the kernel's 128-row tiles and every wave's 64 rows of
+                // vec(A^r) stay inside one matrix column, which is all k_basis_gemm's fused column sums need)
+                bool want = cnt * 2 <= 3L * npad;
+                if (const char* e = getenv("DTO_BASIS_POWERS")) want = atoi(e) != 0;
                 if (want) build_basis(h, b, b.chain_cap);
             }
         }

@@ -166,7 +166,8 @@ def test_ket_infidelity_builtin_kind():
 def test_large_state_shapes_against_the_oracle(n, m, N):
     """The state sizes of BASELINE configs[2..3] (256) and their neighbours, all callbacks incl. the Hessian, on few
     knots so that the oracle (scipy expm/expm_frechet, block-triangular second-order terms) finishes in seconds:
-    128 and 256 take the generator-subspace powers, 192 (not a multiple of 128) the plain GEMM chain."""
+    all three take the generator-subspace powers; 192 (not a multiple of 128) runs the chain on 64x64 tiles.  (The plain
+    three-GEMM power chain is what the 64-state cases above use.)"""
     _check(O.make_scaled_problem(N, n, m, seed=11), tag=f"large-state n={n}")
 
 
