@@ -875,8 +875,16 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
     const int npad = a.w.npad;
     // tile choice: enough workgroups to cover 256 CUs a few times over (the per-step GEMM is small)
     int choice = sweep_tile_choice();
-    if (choice < 0) choice = 5;  // 64x32 measured fastest at 256x2000 (1280 workgroups = 5 per CU: balanced)
-    if (npad % 128 != 0 || a.w.TN != 128) choice = 0;
+    if (choice < 0) {
+        // 64x32 measured fastest at 256x2000 (1280 workgroups = 5 per CU: balanced); smaller problems get 32x32 tiles
+        // so that the launch still covers the chip (-5..10 % per step at 64 and 128 states)
+        const long wgs = (long)(npad / 64) * (a.w.Kpad / 32) * ny;
+        choice = wgs >= 1024 ? 5 : 6;
+    }
+    static const bool relax = [] { const char* e = getenv("DTO_SWEEP_TILE_RELAX"); return !e || atoi(e) != 0; }();
+    if (!relax && (npad % 128 != 0 || a.w.TN != 128)) choice = 0;
+    if ((choice == 3 || choice == 1) && npad % 128 != 0) choice = 0;  // 128-row tiles need npad % 128 == 0
+    if ((choice == 3 || choice == 2) && a.w.Kpad % 128 != 0) choice = 0;
     switch (choice) {
         case 3:
             hipLaunchKernelGGL((k_sweep<128, 128>), dim3((npad / 128) * (a.w.Kpad / 128), ny), dim3(256), 0, st, a);
