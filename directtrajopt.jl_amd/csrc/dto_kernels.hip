@@ -448,6 +448,16 @@ static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_c
 }
 template <int EPI>
 static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
+    // 128x128 tiles (persistent, DMA-staged) win once the launch is large; short trajectories are better served by four
+    // times as many 64x64 workgroups.  Measured crossover (tile-128 workgroups x K panels): 256x200 -17 % with 64-tiles,
+    // 256x500 equal, 256x1000 and 512x100 +5..7 % with 128-tiles (DTO_BGEMM_TILE64=0/1 forces).
+    static const int force64 = [] { const char* e = getenv("DTO_BGEMM_TILE64"); return e ? atoi(e) : -1; }();
+    const long t128 = a.npad / 128;
+    const bool small_launch = force64 >= 0 ? force64 != 0 : t128 * t128 * t128 * a.nbatch < 3500;
+    if (a.npad % 128 == 0 && small_launch && bgemm_shape_choice() < 0) {
+        launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
+        return;
+    }
     if (a.npad % 256 == 0) {
         // shapes measured with tools/bgemm_probe2 (256x2000): see DESIGN.md
         switch (bgemm_shape_choice()) {
