@@ -400,6 +400,12 @@ struct Bounds {
     double beta, b1;
 };
 
+// enqueue only: the two doubles land in h_pinned[0..1] in stream order (read them after a later synchronisation point)
+void enqueue_bounds(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
+    HIP_CHECK(hipMemsetAsync(h->d_bounds, 0, 2 * sizeof(double), st));
+    launch_norm_bounds(st, h->P, b.k, dZ, b.d_g1, b.d_n2, reinterpret_cast<unsigned long long*>(h->d_bounds));
+    HIP_CHECK(hipMemcpyAsync(h->h_pinned, h->d_bounds, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+}
 Bounds get_bounds(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(h->d_bounds, 0, 2 * sizeof(double), st));
     launch_norm_bounds(st, h->P, b.k, dZ, b.d_g1, b.d_n2, reinterpret_cast<unsigned long long*>(h->d_bounds));
@@ -610,7 +616,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     if (nint <= 0) return d2max;
     const int cap = b.chain_cap;
     int s_ub = 1;
-    if (b1max == b1max && b1max > THETA_16) s_ub = std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
+    if (b1max == b1max && b1max > THETA_16) s_ub = std::isinf(b1max) ? 60 : std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
     s_ub = std::min(s_ub, 60);
     const double gemm_flops = 2.0 * npad * (double)npad * npad;
     h->last_smax = 0;
@@ -825,14 +831,17 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
         }
         Bounds bd{0, 0};
         if (h->P.n_int > 0) {
-            bd = get_bounds(h, b, dZ, st);
+            // generator-norm bounds: enqueued here, read inside the chain's own readback point (no stream sync of their
+            // own); the squaring cap they used to provide is the constant 60, a NaN iterate gets one squaring
+            enqueue_bounds(h, b, dZ, st);
             static const bool overlap = [] { const char* e = getenv("DTO_OVERLAP"); return e && atoi(e) != 0; }();  // off by default: +2% end to end, but per-kernel timings blur
             hipStream_t ss = overlap ? h->stream2 : st;
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
                 HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
             }
-            run_chain(h, b, dZ, dvals, bd.b1, st, [&](double d2) {
+            run_chain(h, b, dZ, dvals, INFINITY, st, [&](double d2) {
+                bd = Bounds{h->h_pinned[0], h->h_pinned[1]};  // copied before the chain's readback event
                 // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
                 // (and still rigorous) growth rate for the sweep's step budget
                 SweepPlan plan = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);

@@ -606,7 +606,8 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
         s = (int)ceil(log2(alpha / THETA_16));
         if (s < 1) s = 1;
     }
-    if (!(alpha == alpha) || s > s_cap) s = s_cap;  // NaN/Inf input: bounded work, NaN propagates
+    if (s > s_cap) s = s_cap;          // huge norm: bounded work
+    if (!(alpha == alpha)) s = 1;      // NaN input: one squaring, the NaN propagates to the output
     w.s[b] = s;
     atomicMax(&w.smax[0], s);
     atomicAdd(&w.smax[1], s);
