@@ -70,6 +70,9 @@ struct BilHost {
     double hump_logH[4] = {0, 0, 0, 0};
     int hump_kend[4] = {0, 0, 0, 0};
     bool hump_valid = false;
+    // reuse_forward_sweep: what b.fw still holds for the cached Z -- 0 nothing, 1 the p sums (S type 0), 2 p and d^j sums
+    // and GY, 3 additionally every Taylor term in fw.Zt (cache_steps of them)
+    int cache_kind = 0, cache_steps = 0;
     bool small = false;       // n <= 32: fused one-workgroup-per-interval path (dto_small.hip)
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
@@ -171,6 +174,9 @@ struct dto_handle {
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr, ev_chain = nullptr;
 
+    bool reuse = false;          // option reuse_forward_sweep
+    double* d_Zcache = nullptr;  // the Z the cached sweeps belong to
+    int32_t* d_eq = nullptr;
     bool profiling = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;  // recycled timing events (creating them inside the timed region costs host time)
@@ -769,6 +775,29 @@ SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st)
 // callbacks (device-pointer forms)
 // ------------------------------------------------------------------------------------------
 
+// reuse_forward_sweep: is dZ bit-identical to the point the cached sweeps were computed at?  If not, dZ becomes the new
+// cache point and every integrator's cache is dropped.
+bool same_point(dto_handle* h, const double* dZ, hipStream_t st) {
+    if (!h->reuse) return false;
+    if (!h->d_Zcache) {
+        h->d_Zcache = own(h, dalloc<double>((size_t)h->n_vars));
+        h->d_eq = own(h, dalloc<int32_t>(1));
+        HIP_CHECK(hipMemcpyAsync(h->d_Zcache, dZ, sizeof(double) * (size_t)h->n_vars, hipMemcpyDeviceToDevice, st));
+        for (auto& b : h->bil) b.cache_kind = 0;
+        return false;
+    }
+    int32_t* flag = reinterpret_cast<int32_t*>(h->h_pinned + 24);
+    *flag = 1;
+    HIP_CHECK(hipMemcpyAsync(h->d_eq, flag, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    launch_bits_equal(st, dZ, h->d_Zcache, h->n_vars, h->d_eq);
+    HIP_CHECK(hipMemcpyAsync(flag, h->d_eq, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (*flag) return true;
+    HIP_CHECK(hipMemcpyAsync(h->d_Zcache, dZ, sizeof(double) * (size_t)h->n_vars, hipMemcpyDeviceToDevice, st));
+    for (auto& b : h->bil) b.cache_kind = 0;
+    return false;
+}
+
 // copy one of the caller's arrays of an external term (dto_set_external) into its device staging buffer
 const double* ext_upload(dto_handle* h, int slot, int which, hipStream_t st) {
     ExtSlot& e = h->ext[slot];
@@ -797,15 +826,19 @@ void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st)
 }
 
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
+    const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
         if (b.small) {
             launch_small(st, h->P, b.k, b.d_Gs, make_types(0, false), make_types(0, false), dZ, nullptr, dg, nullptr, nullptr, 1);
             continue;
         }
         if (h->P.n_int > 0) {
-            SweepPlan plan = plan_from(h, b, dZ, st);
-            SweepTypes ty = make_types(0, false);
-            run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
+            if (!(same && b.cache_kind >= 1)) {  // else exp(A)x of this very point is still in b.fw.S
+                SweepPlan plan = plan_from(h, b, dZ, st);
+                SweepTypes ty = make_types(0, false);
+                run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
+                b.cache_kind = h->reuse ? 1 : 0;
+            }
             launch_cons_bilinear(st, h->P, b.k, b.fw, dZ, dg);
         }
     }
@@ -824,6 +857,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
     if (h->bil.size() == 1 && h->P.n_int > 0 && !h->bil[0].small) launch_jac_zero(st, h->P, h->bil[0].k, dvals);
     else HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
     h->last_terms = 0;
+    const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
         if (b.small) {
             launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, false), make_types(0, false), dZ, nullptr, nullptr, dvals, nullptr, 2);
@@ -844,10 +878,15 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 bd = Bounds{h->h_pinned[0], h->h_pinned[1]};  // copied before the chain's readback event
                 // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
                 // (and still rigorous) growth rate for the sweep's step budget
+                if (same && b.cache_kind >= 2) return;  // the tangent sums of this very point are still in b.fw
                 SweepPlan plan = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);
                 SweepTypes ty = make_types(b.k.m, false);
-                run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss);
+                // with reuse on and a Hessian to follow, keep every Taylor term so that the Hessian can skip its forward sweep
+                const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
+                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep);
                 launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+                b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
+                b.cache_steps = steps;
             });
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_join, ss));
@@ -867,6 +906,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
 
 void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dH, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, st));  // fill!(H, 0), evaluator.jl:571
+    const bool same = same_point(h, dZ, st);
     // integrators in reference order (evaluator.jl:574-598)
     for (size_t i = 0; i < h->integ_kind.size(); ++i) {
         if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) {
@@ -879,8 +919,15 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             SweepPlan plan = plan_from(h, b, dZ, st);
             const bool pair = b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
             SweepTypes ty2 = make_types(b.k.m, !pair);
-            const int steps_f = run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st, pair);
-            launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+            int steps_f;
+            if (pair && same && b.cache_kind == 3) {
+                steps_f = b.cache_steps;  // forward terms, sums and G(u)y of this very point are still in b.fw
+            } else {
+                steps_f = run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st, pair);
+                launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+                b.cache_kind = (h->reuse && pair) ? 3 : 0;
+                b.cache_steps = steps_f;
+            }
             // W_j = G_j' mu from the adjoint sweep's term-0 buffer, then the adjoint sweep itself
             launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
             launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
@@ -1674,6 +1721,7 @@ static void jac_product_matrix_free(dto_handle* h, const double* dZ, const doubl
     HIP_CHECK(hipMemsetAsync(dy, 0, sizeof(double) * (size_t)n_out, st));  // fill!(y, 0), evaluator.jl:416,442
     for (auto& b : h->bil) {
         if (h->P.n_int <= 0) continue;
+        b.cache_kind = 0;  // the product sweeps use b.fw with their own column types
         SweepPlan plan = plan_from(h, b, dZ, st);
         SweepTypes ty = make_types(b.k.m, false);
         if (!transpose) {
@@ -1750,6 +1798,16 @@ int dto_eval_jacobian_transpose_product(dto_handle* h, const double* Z, const do
 }
 
 // ---- measurement
+int dto_set_option(dto_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return 1;
+    if (std::string(name) == "reuse_forward_sweep") {
+        h->reuse = value != 0;
+        for (auto& b : h->bil) b.cache_kind = 0;
+        return 0;
+    }
+    return fail(h, std::string("dto_set_option: unknown option ") + name);
+}
+
 int dto_profile_enable(dto_handle* h, int32_t on) {
     if (!h) return 1;
     if (on && !h->structure_only && h->ev_pool.size() < 1024) {

@@ -266,6 +266,8 @@ struct KIntegTable {
 void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
                      const double* vals, const double* w, double* y, int transpose, int64_t global_cols = 0);
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n);  // dst += src
+// *flag = 0 if a and b differ in any bit (flag preset to 1 by the caller)
+void launch_bits_equal(hipStream_t st, const double* a, const double* b, int64_t n, int32_t* flag);
 
 // Powers of A_k from the generator subspace: A_k = dt*sum_j ubar_j G_j lives in an (m+1)-dimensional
 // matrix space, so A_k^r = sum over multisets alpha of size r of (dt^r prod ubar_alpha) * S_alpha with

@@ -65,6 +65,16 @@ __global__ void k_add(double* __restrict__ dst, const double* __restrict__ src, 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) dst[i] += src[i];
 }
+__global__ void k_bits_equal(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n,
+                             int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) *flag = 0;
+}
+void launch_bits_equal(hipStream_t st, const double* a, const double* b, int64_t n, int32_t* flag) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_bits_equal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned long long*>(a), reinterpret_cast<const unsigned long long*>(b), n, flag);
+}
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n) {
     if (n <= 0) return;
     int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

@@ -85,6 +85,7 @@ SYMBOLS = {
     "dto_eval_constraint_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dto_eval_jacobian_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dto_eval_hessian_dev": (C.c_int, [H, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dto_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "dto_profile_enable": (C.c_int, [H, C.c_int32]),
     "dto_profile_reset": (C.c_int, [H]),
     "dto_profile_get": (C.c_int, [H, C.c_char_p, c_double_p, c_int64_p, c_double_p]),

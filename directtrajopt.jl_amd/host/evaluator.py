@@ -352,6 +352,10 @@ class Evaluator:
         self._stage_external(Z_host, con_need=2, obj_need=2 if sigma != 0.0 else -1, mu=mu_host)
         self._check(self._lib.dto_eval_hessian_dev(self._h, dZ, float(sigma), dmu, dvals, stream))
 
+    def set_option(self, name, value):
+        """dto_set_option: e.g. ``reuse_forward_sweep`` (solver loops evaluate g, J, H at the same point)."""
+        self._check(self._lib.dto_set_option(self._h, name.encode(), int(value)))
+
     # ---- measurement
     def profile_enable(self, on=True):
         self._check(self._lib.dto_profile_enable(self._h, int(on)))

@@ -227,6 +227,15 @@ int dto_eval_jacobian_dev(dto_handle* h, const double* dZ, double* dvals, void* 
 int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const double* dmu,
                          double* dvals, void* stream);
 
+/* Options (name, value); unknown names are an error.
+ *   "reuse_forward_sweep" (default 0): interior-point solvers evaluate g, J and H at the same point one after the
+ *   other.  With this on, the engine remembers the forward generator sweep of the last callback and re-uses it when
+ *   the next callback's Z is bit-identical (compared on the device, one 4-byte readback): eval_constraint after
+ *   eval_jacobian then costs a copy, eval_hessian skips its forward sweep.  Results agree to rounding either way (the constraint-only
+ *   sweep sums its generator products in a different order than the Jacobian's); the benchmark never turns it on (each
+ *   callback is timed cold). */
+int dto_set_option(dto_handle* h, const char* name, int64_t value);
+
 /* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */
 int dto_profile_enable(dto_handle* h, int32_t on);
 int dto_profile_reset(dto_handle* h);

@@ -204,3 +204,49 @@ def test_matrix_free_products_on_the_general_path():
         assert rel_err(y, ev_o.eval_constraint_jacobian_product(p.Z0, w)) <= 1e-10
         assert rel_err(yt, ev_o.eval_constraint_jacobian_transpose_product(p.Z0, v)) <= 1e-10
         ev.close()
+
+
+def test_reuse_forward_sweep_between_callbacks():
+    """Option reuse_forward_sweep: g, J, H evaluated one after the other at the same point (what an interior-point
+    iteration does) share the forward generator sweep; every ordering, with the point changing in between, must give
+    the same numbers as a handle without the option."""
+    import dto_amd
+    import dto_oracle as O
+    from helpers import rel_err, to_engine
+    p = O.make_scaled_problem(6, 40, 2, seed=17, with_constraint=True)  # general path (n > 32)
+    ref = dto_amd.Evaluator(to_engine(p))
+    ev = dto_amd.Evaluator(to_engine(p))
+    ev.set_option("reuse_forward_sweep", 1)
+    with pytest.raises(dto_amd.EngineError):
+        ev.set_option("no_such_option", 1)
+    rng = np.random.default_rng(0)
+    Z1 = p.Z0.copy()
+    Z2 = p.Z0 + 0.05 * rng.standard_normal(p.n_vars)
+    mu = rng.standard_normal(ref.n_constraints)
+
+    def calls(e, Z):
+        g = np.empty(e.n_constraints); e.eval_constraint(g, Z)
+        J = np.empty(e.n_jacobian_entries); e.eval_constraint_jacobian(J, Z)
+        H = np.empty(e.n_hessian_entries); e.eval_hessian_lagrangian(H, Z, 0.9, mu)
+        return {"g": g, "J": J, "H": H}
+
+    try:
+        want = {id(Z): calls(ref, Z) for Z in (Z1, Z2)}
+        orders = [("g", "J", "H"), ("J", "g", "H"), ("H", "J", "g"), ("J", "H", "J", "g"), ("g", "g", "H", "H")]
+        for order in orders:
+            for Z in (Z1, Z2, Z1):
+                for what in order:
+                    if what == "g":
+                        out = np.empty(ev.n_constraints); ev.eval_constraint(out, Z)
+                    elif what == "J":
+                        out = np.empty(ev.n_jacobian_entries); ev.eval_constraint_jacobian(out, Z)
+                    else:
+                        out = np.empty(ev.n_hessian_entries); ev.eval_hessian_lagrangian(out, Z, 0.9, mu)
+                    # (the constraint-only sweep splits K by generator: same terms, different summation order)
+                    assert rel_err(out, want[id(Z)][what]) <= 1e-13, (order, what)
+        # products in between must not leave a stale cache behind
+        y = np.empty(ev.n_constraints); ev.eval_constraint_jacobian_product(y, Z1, rng.standard_normal(p.n_vars))
+        out = np.empty(ev.n_constraints); ev.eval_constraint(out, Z1)
+        assert rel_err(out, want[id(Z1)]["g"]) <= 1e-13
+    finally:
+        ref.close(); ev.close()
