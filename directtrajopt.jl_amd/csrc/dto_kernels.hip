@@ -555,9 +555,17 @@ void launch_beta_from_norms(hipStream_t st, int nb, const ChainWork& w) {
 // k >= p(p-1)).  log hump(q) bounds the digits the sums can lose to cancellation; the sweep runs in q rounds with the
 // smallest q whose hump stays below e^theta_v.  out[q-1] = max_k log hump(q) (bit pattern of a non-negative double),
 // out[4+q-1] = max_k (last term index with best[k]/(q^k k!) >= 1e-19), q = 1..4.
-__global__ void k_hump(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1, int64_t int0, int nb,
-                       const double* __restrict__ norms, unsigned long long* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_hump(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1,
+                                              int64_t int0, int nb, const double* __restrict__ norms,
+                                              unsigned long long* __restrict__ out) {
+    __shared__ double lfact[161];  // log k!: one log per thread once, instead of one per (interval, q, k)
+    if (threadIdx.x <= 160) lfact[threadIdx.x] = threadIdx.x ? log((double)threadIdx.x) : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 1; k <= 160; ++k) lfact[k] += lfact[k - 1];
+    __syncthreads();
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (interval, q): four threads per interval
+    const int b = gid >> 2, q = (gid & 3) + 1;
     if (b >= nb) return;
     const double* zk = Z + (int0 + b) * P.z;
     double n1 = g1[0];
@@ -568,29 +576,27 @@ __global__ void k_hump(KProb P, KBil B, const double* __restrict__ Z, const doub
     N[2] = norms[b * 4 + 1]; N[3] = norms[b * 4 + 2]; N[4] = norms[b * 4 + 3];
     bool bad = !(n1 == n1);
     for (int p = 2; p <= 4; ++p) bad = bad || !(N[p] == N[p]);
-    for (int q = 1; q <= 4; ++q) {
-        double lN[5];
-        for (int p = 1; p <= 4; ++p) lN[p] = (N[p] > 0.0 ? log(N[p]) : -700.0) - p * log((double)q);  // log(inf) = inf: unused
-        double lb[4] = {0.0, 0.0, 0.0, 0.0};  // lb[(k - i) & 3]: log best of the last four k
-        double logH = 0.0, lfact = 0.0;
-        int kend = 0;
-        for (int k = 1; k <= 160; ++k) {
-            double v = INFINITY;
-            for (int p = 1; p <= 4 && p <= k; ++p) v = fmin(v, lb[(k - p) & 3] + lN[p]);
-            lb[k & 3] = v;
-            lfact += log((double)k);
-            const double lt = v - lfact;
-            logH = fmax(logH, lt);
-            if (lt >= -43.75) kend = k;  // 1e-19
-        }
-        if (bad) { logH = __longlong_as_double(0x7ff8000000000000ll); kend = 160; }
-        atomicMax(&out[q - 1], dbits(logH));
-        atomicMax(&out[4 + q - 1], (unsigned long long)kend);
+    double lN[5];
+    const double lq = log((double)q);
+    for (int p = 1; p <= 4; ++p) lN[p] = (N[p] > 0.0 ? log(N[p]) : -700.0) - p * lq;  // log(inf) = inf: unused
+    double lb[4] = {0.0, 0.0, 0.0, 0.0};  // lb[(k - i) & 3]: log best of the last four k
+    double logH = 0.0;
+    int kend = 0;
+    for (int k = 1; k <= 160; ++k) {
+        double v = INFINITY;
+        for (int p = 1; p <= 4 && p <= k; ++p) v = fmin(v, lb[(k - p) & 3] + lN[p]);
+        lb[k & 3] = v;
+        const double lt = v - lfact[k];
+        logH = fmax(logH, lt);
+        if (lt >= -43.75) kend = k;  // 1e-19
     }
+    if (bad) { logH = __longlong_as_double(0x7ff8000000000000ll); kend = 160; }
+    atomicMax(&out[q - 1], dbits(logH));
+    atomicMax(&out[4 + q - 1], (unsigned long long)kend);
 }
 void launch_hump(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, const double* g1, int64_t int0, int nb,
                  const double* norms, unsigned long long* out) {
-    hipLaunchKernelGGL(k_hump, dim3((nb + 127) / 128), dim3(128), 0, st, P, B, dZ, g1, int0, nb, norms, out);
+    hipLaunchKernelGGL(k_hump, dim3((4 * nb + 255) / 256), dim3(256), 0, st, P, B, dZ, g1, int0, nb, norms, out);
 }
 void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w) {
     hipLaunchKernelGGL(k_norm1, dim3(nb, 4), dim3(256), 0, st, npad, w, -1);
