@@ -558,15 +558,13 @@ void launch_beta_from_norms(hipStream_t st, int nb, const ChainWork& w) {
 __global__ void __launch_bounds__(256) k_hump(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1,
                                               int64_t int0, int nb, const double* __restrict__ norms,
                                               unsigned long long* __restrict__ out) {
-    __shared__ double lfact[161];  // log k!: one log per thread once, instead of one per (interval, q, k)
-    if (threadIdx.x <= 160) lfact[threadIdx.x] = threadIdx.x ? log((double)threadIdx.x) : 0.0;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int k = 1; k <= 160; ++k) lfact[k] += lfact[k - 1];
+    __shared__ double logk[161];  // log k: one log per thread once, instead of one per (interval, q, k)
+    if (threadIdx.x <= 160) logk[threadIdx.x] = threadIdx.x ? log((double)threadIdx.x) : 0.0;
     __syncthreads();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (interval, q): four threads per interval
-    const int b = gid >> 2, q = (gid & 3) + 1;
-    if (b >= nb) return;
+    const int q = (gid & 3) + 1;
+    const bool live = (gid >> 2) < nb;
+    const int b = live ? gid >> 2 : nb - 1;  // surplus lanes repeat the last interval (they take part in the wave reduction)
     const double* zk = Z + (int0 + b) * P.z;
     double n1 = g1[0];
     for (int j = 0; j < B.m; ++j) n1 += fabs(zk[B.u_off + j]) * g1[1 + j];
@@ -579,20 +577,33 @@ __global__ void __launch_bounds__(256) k_hump(KProb P, KBil B, const double* __r
     double lN[5];
     const double lq = log((double)q);
     for (int p = 1; p <= 4; ++p) lN[p] = (N[p] > 0.0 ? log(N[p]) : -700.0) - p * lq;  // log(inf) = inf: unused
-    double lb[4] = {0.0, 0.0, 0.0, 0.0};  // lb[(k - i) & 3]: log best of the last four k
-    double logH = 0.0;
+    double b0 = 0.0, b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;  // log best[k-1 .. k-4] (best[0] = 1, none before it)
+    double logH = 0.0, lfact = 0.0;
+    // per-step growth of log best is at most max_p lN[p]/p: once log k exceeds it the terms only shrink
+    const double rate = fmax(fmax(lN[1], 0.5 * lN[2]), fmax(lN[3] * (1.0 / 3.0), 0.25 * lN[4]));
     int kend = 0;
     for (int k = 1; k <= 160; ++k) {
-        double v = INFINITY;
-        for (int p = 1; p <= 4 && p <= k; ++p) v = fmin(v, lb[(k - p) & 3] + lN[p]);
-        lb[k & 3] = v;
-        const double lt = v - lfact[k];
+        const double v = fmin(fmin(b0 + lN[1], b1 + lN[2]), fmin(b2 + lN[3], b3 + lN[4]));
+        b3 = b2; b2 = b1; b1 = b0; b0 = v;
+        lfact += logk[k];
+        const double lt = v - lfact;
         logH = fmax(logH, lt);
         if (lt >= -43.75) kend = k;  // 1e-19
+        else if (logk[k] > rate) break;
     }
     if (bad) { logH = __longlong_as_double(0x7ff8000000000000ll); kend = 160; }
-    atomicMax(&out[q - 1], dbits(logH));
-    atomicMax(&out[4 + q - 1], (unsigned long long)kend);
+    // lanes with equal q (equal low two bits) reduce first: eight atomics per wavefront instead of 128 on eight addresses
+    unsigned long long hb = dbits(logH), kb = (unsigned long long)kend;
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+        const unsigned long long h2 = __shfl_xor(hb, o, 64), k2 = __shfl_xor(kb, o, 64);
+        hb = h2 > hb ? h2 : hb;
+        kb = k2 > kb ? k2 : kb;
+    }
+    if ((threadIdx.x & 63) < 4) {
+        atomicMax(&out[q - 1], hb);
+        atomicMax(&out[4 + q - 1], kb);
+    }
 }
 void launch_hump(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, const double* g1, int64_t int0, int nb,
                  const double* norms, unsigned long long* out) {
