@@ -77,7 +77,7 @@ struct BilHost {
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
     BasisSet basis[3]{};      // degrees 2, 3, 4
-    BasisSet basis_all{};     // every multiset of degree 0..4: one GEMM gives the bracket H3
+    BasisSet basis_all{};     // every multiset of degree 0..4: one GEMM gives the factor K of the two-product Taylor form
     // Hessian pairing path: stored Taylor terms of both sweeps, E_j * forward terms, Beta-weighted adjoint sums
     bool pairing = false;
     double* EP = nullptr;
@@ -553,7 +553,7 @@ void build_basis(dto_handle* h, BilHost& b, int cap) {
         bs.coef = own(h, dalloc<double>((size_t)cappad * cntpad));
     }
     {
-        // concatenation [I | G_0..G_m | S2 | S3 | S4] for the H3 bracket
+        // concatenation [I | G_0..G_m | S2 | S3 | S4] for the factor K
         int cnt = 1 + m1;
         for (int r = 2; r <= 4; ++r) cnt += (int)sets[r].size();
         const int cntpad = ((cnt + 15) / 16) * 16;
@@ -585,7 +585,7 @@ void build_basis(dto_handle* h, BilHost& b, int cap) {
 
 void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     const size_t nn = (size_t)b.k.npad * b.k.npad;
-    for (int i = 0; i < 6; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
+    for (int i = 0; i < 7; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
     b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
     b.chain.colsum = own(h, dalloc<double>((size_t)3 * cap * b.k.npad));
     if (!b.d_hump) b.d_hump = own(h, dalloc<unsigned long long>(8));
@@ -598,13 +598,13 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
 }
 
 int chunk_size(const dto_handle* h, int npad) {
-    // workspace budget for the 6 chain matrices; DTO_CHAIN_CHUNK overrides
+    // workspace budget for the 7 chain matrices; DTO_CHAIN_CHUNK overrides
     if (const char* e = getenv("DTO_CHAIN_CHUNK")) {
         int v = atoi(e);
         if (v > 0) return v;
     }
-    const double budget = 24e9;
-    int c = (int)(budget / (6.0 * npad * (double)npad * 8.0));
+    const double budget = 28e9;
+    int c = (int)(budget / (7.0 * npad * (double)npad * 8.0));
     c = std::max(8, (c / 8) * 8);
     return (int)std::min<int64_t>(c, std::max<int64_t>(h->P.n_int, 1));
 }
@@ -612,7 +612,7 @@ int chunk_size(const dto_handle* h, int npad) {
 // exp(dt G(u_k)) for every owned interval; -E_k goes straight into the Jacobian slab.
 // Returns max_k ||A_k^2||_1^(1/2) (exact), which bounds the growth of the Taylor terms of the sweep.
 // `after_last_enqueue(d2max)` runs on the host once every kernel of the chain has been enqueued (the GPU
-// is then busy with Horner products and squarings): the caller uses it to drive the generator sweep on a
+// is then busy with the Taylor products and squarings): the caller uses it to drive the generator sweep on a
 // second stream so that both proceed concurrently.
 double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st,
                  const std::function<void(double)>& after_last_enqueue = nullptr) {
@@ -655,7 +655,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         if (c0 == 0) HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
         launch_hump(st, h->P, b.k, dZ, b.d_g1, int0, nb, w.norms, b.d_hump);
         // the number of squaring launches is data dependent: read back max/sum of s_k (8 bytes) while
-        // the Horner products run
+        // the two Taylor products run
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
         HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -669,9 +669,9 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         } else {
             launch_poly_h3(st, npad, nb, w);
         }
-        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 8); }
-        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 4, 5, 4); }
-        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_horner(st, npad, nb, w, 5, 4, 0); }
+        // Y = A^4 K -> (Y + Pa, Y + Pb) in one launch, then T_16 = (Y + Pa)(Y + Pb) + Pc
+        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 3, 5, 4, COEF_PA, 6, COEF_PB); }
+        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 4, 6, 5, COEF_PC, -1, 0); }
         HIP_CHECK(hipEventSynchronize(ev_s));
         const int s_max = hs[0];
         read_hump(h, b);  // accumulated over the chunks so far; final after the last one
@@ -682,7 +682,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         }
         const double sq_flops = s_max > 0 ? gemm_flops * (double)hs[1] / s_max : 0.0;
         h->last_smax = std::max(h->last_smax, s_max);
-        int src = 4;
+        int src = 5;
         for (int it = 0; it < s_max; ++it) {
             ProfScope ps(h, st, CAT_BGEMM_SQUARE, sq_flops);
             launch_bgemm_square(st, npad, nb, w, src, src == 4 ? 5 : 4, it, h->P, b.k, int0, vals);

@@ -9,6 +9,16 @@ namespace dto {
 constexpr int TAYLOR_M = 16;                 // degree of the matrix Taylor polynomial
 constexpr double THETA_16 = 0.78028743;      // backward-error radius of T_16 in double (Al-Mohy & Higham 2011, Table 3.1 method)
 constexpr int COEF_STRIDE = 20;              // doubles per interval in the coefficient table
+// T_16(B) = sum_{r<=16} B^r/r! with TWO products once B..B^4 are known (they come from the generator subspace):
+//   Y = B^4 K(B),   T_16(B) = (Y + Pa(B)) (Y + Pb(B)) + Pc(B),   K, Pa, Pb, Pc of degree <= 4
+// (Paterson-Stockmeyer needs three).  Constants from tools/expm_two_product_coeffs.py: the polynomial identity solved to
+// 1e-50, factors without cancellation (sum of |terms| / exp = 1.03 at the radius); rounding error at ||B||_1 = 0.78:
+// 6e-16 against 2e-16 for the Horner form.  Table layout per interval (each entry times its power of sigma = 2^-s):
+constexpr int COEF_PC = 0, COEF_PA = 5, COEF_PB = 10, COEF_K = 15;
+constexpr double EXPM2_K[5] = {0.0021247619694343247, 0.00021337327385069214, 1.9238573871783716e-05, 1.748961261071247e-06, 2.1862015763390587e-07};
+constexpr double EXPM2_A[5] = {0.15657629060017847, 0.11131927651852432, 0.04459108138499527, 0.00629379053080652, -0.00037523326035530425};
+constexpr double EXPM2_B[5] = {6.392946474783064, 1.8714151425525498, 0.2847453199197648, 0.035205562271892026, 0.0005680709246076226};
+constexpr double EXPM2_C[5] = {-0.000983845027019532, -0.004677417588383601, -0.03797734224052902, 0.005772376398520401, 0.0016659351281941514};
 constexpr int MAX_TYPES = 36;                // column types of a generator sweep (p, d^i, h^{ij})
 constexpr int MAX_DRIVES = 7;
 
@@ -99,7 +109,7 @@ struct SweepTypes {
 
 // ------------------------------------------------------------------ launch wrappers (dto_kernels.hip)
 struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices npad x npad each
-    double* W[6];    // A, A2, A3, A4, Ha, Hb
+    double* W[7];    // A, A2, A3, A4, then Y+Pa / squaring ping, K / T_16 / squaring pong, Y+Pb
     double* norms;   // [C][4]
     double* colsum;  // [3][C][npad] column abs-sums of A^2..A^4 (basis path)
     double* coef;    // [C][COEF_STRIDE]
@@ -115,7 +125,9 @@ void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w);
 void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int which);
 void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w);
 void launch_poly_h3(hipStream_t st, int npad, int nb, const ChainWork& w);
-void launch_bgemm_horner(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int coef_base);
+// W[dst] = W[srcA] W[srcB] + poly(coef_base);  dst2 >= 0: also W[dst2] = W[srcA] W[srcB] + poly(coef_base2)
+void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int srcA, int srcB, int dst, int coef_base,
+                       int dst2, int coef_base2);
 void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
                          const KProb& P, const KBil& B, int64_t int0, double* vals);
 

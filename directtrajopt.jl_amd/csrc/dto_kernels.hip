@@ -82,9 +82,9 @@ void launch_add(hipStream_t st, double* dst, const double* src, int64_t n) {
 }
 
 // coef[b][alpha] = dt^r * prod_{i in alpha} ubar_i  (zero for padded intervals / padded multisets)
-// H3 mode (taylor != nullptr): the set holds every multiset of degree 0..4 (idx padded with -1) and the
-// coefficient of a degree-r multiset is c_{12+r} sigma^{12+r} dt^r prod ubar, i.e. the output is the innermost
-// Paterson-Stockmeyer bracket H3 = c12 I + c13 A + c14 A^2 + c15 A^3 + c16 A^4.
+// K mode (taylor != nullptr): the set holds every multiset of degree 0..4 (idx padded with -1) and the
+// coefficient of a degree-r multiset is k_r sigma^{4+r} dt^r prod ubar, i.e. the output is the right factor
+// K = k0 I + k1 A + ... + k4 A^4 of the two-product Taylor evaluation (Y = A^4 K).
 __global__ void k_basis_coef(KProb P, KBil B, BasisSet bs, const double* __restrict__ Z, int64_t int0, int nb,
                              const double* __restrict__ taylor) {
     const int b = blockIdx.x;
@@ -107,7 +107,7 @@ __global__ void k_basis_coef(KProb P, KBil B, BasisSet bs, const double* __restr
                 v *= dt;
                 if (g > 0) v *= zk[B.u_off + g - 1];
             }
-            if (taylor) v *= taylor[(int64_t)b * COEF_STRIDE + 12 + deg];
+            if (taylor) v *= taylor[(int64_t)b * COEF_STRIDE + COEF_K + deg];
         }
         c[a] = v;
     }
@@ -317,19 +317,22 @@ void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double*
     hipLaunchKernelGGL(k_build_A, dim3(gx, nb), dim3(256), 0, st, P, B, dZ, int0, A);
 }
 
-enum { EPI_PLAIN = 0, EPI_HORNER = 1, EPI_SQUARE = 2 };
+enum { EPI_PLAIN = 0, EPI_HORNER = 1, EPI_SQUARE = 2, EPI_DUAL = 3 };  // HORNER: + degree-4 polynomial; DUAL: two such outputs
 
 struct BGemmArgs {
     const double* A;
     const double* B;
     double* C;
     int npad, nbatch;
-    // horner: C = A*B + c0 I + c1 M1 + c2 M2 + c3 M3
+    // poly: C = A*B + c0 I + c1 M1 + c2 M2 + c3 M3 + c4 M4, and (C2 != nullptr) C2 = A*B + the same with the
+    // coefficients at coef_base2: both factors of the two-product Taylor evaluation leave one launch
     const double* M1;
     const double* M2;
     const double* M3;
+    const double* M4;
     const double* coef;
-    int coef_base;
+    int coef_base, coef_base2;
+    double* C2;
     // square
     const int32_t* s;
     int it;
@@ -394,12 +397,18 @@ k_bgemm(BGemmArgs a) {
         }
 
         double* Cb = a.C + b * nn;
-        double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr;
-        if (EPI == EPI_HORNER) {
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr;
+        double* Cb2 = nullptr;
+        if (EPI == EPI_HORNER || EPI == EPI_DUAL) {
             const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
-            c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3];
-            M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn;
+            c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
+            M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn; M4 = a.M4 + b * nn;
+            if (EPI == EPI_DUAL) {
+                const double* ef = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base2;
+                e0 = ef[0]; e1 = ef[1]; e2 = ef[2]; e3 = ef[3]; e4 = ef[4];
+                Cb2 = a.C2 + b * nn;
+            }
         }
 #pragma unroll
         for (int tj = 0; tj < Cfg::NT; ++tj)
@@ -411,13 +420,20 @@ k_bgemm(BGemmArgs a) {
                     const int row = row0 + 16 * ti;
                     const int64_t off = (int64_t)col * a.npad + row;
                     double v2 = acc.v[ti][tj][r];
-                    if (EPI == EPI_HORNER) {
-                        v2 += c1 * __builtin_nontemporal_load(&M1[off]) + c2 * __builtin_nontemporal_load(&M2[off]) +
-                              c3 * __builtin_nontemporal_load(&M3[off]);  // streamed once per stage
+                    if (EPI == EPI_HORNER || EPI == EPI_DUAL) {
+                        const double m1 = __builtin_nontemporal_load(&M1[off]), m2 = __builtin_nontemporal_load(&M2[off]),
+                                     m3 = __builtin_nontemporal_load(&M3[off]), m4 = M4[off];  // M4 is also this launch's A operand
+                        if (EPI == EPI_DUAL) {
+                            double w2 = v2 + (e1 * m1 + e2 * m2 + e3 * m3 + e4 * m4);
+                            if (row == col) w2 += e0;
+                            __builtin_nontemporal_store(w2, &Cb2[off]);
+                        }
+                        v2 += c1 * m1 + c2 * m2 + c3 * m3 + c4 * m4;  // streamed once per stage
                         if (row == col) v2 += c0;
                     }
                     __builtin_nontemporal_store(v2, &Cb[off]);  // 1 GB per launch: gone from L2 before its reader starts
                 }
+                if (EPI == EPI_DUAL) __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later columns from piling up (spills)
             }
     }
 }
@@ -443,12 +459,12 @@ template <class Cfg, int EPI>
 static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_cu) {
     int grid = batch_tile_count(a.nbatch, (a.npad / Cfg::TM) * (a.npad / Cfg::TN));
     int wgs = bgemm_wgs_choice();
-    if (wgs < 0) wgs = EPI == EPI_HORNER ? 0 : wgs_per_cu;
+    if (wgs < 0) wgs = (EPI == EPI_HORNER || EPI == EPI_DUAL) ? 0 : wgs_per_cu;
     else if (wgs > 0) wgs = wgs_per_cu;
     if (wgs > 0 && grid > wgs * 256) grid = wgs * 256;
     if constexpr (Cfg::TM == 128 && Cfg::TN == 128 && Cfg::KB == 16) {
         int dma = bgemm_dma_choice();
-        if (dma < 0) dma = EPI == EPI_HORNER ? 0 : 1;
+        if (dma < 0) dma = (EPI == EPI_HORNER || EPI == EPI_DUAL) ? 0 : 1;
         if (dma) {
             hipLaunchKernelGGL((k_bgemm<Cfg, EPI, true>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
             return;
@@ -483,12 +499,12 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
             default:
                 // measured in the engine (256x2000): the fused-polynomial epilogue hides better behind 8 waves,
                 // the plain / squaring products run faster with 4 waves of 64x64
-                if (EPI == EPI_HORNER) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+                if (EPI == EPI_HORNER || EPI == EPI_DUAL) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
                 else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
                 return;
         }
     } else if (a.npad % 128 == 0) {
-        if (EPI == EPI_HORNER) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+        if (EPI == EPI_HORNER || EPI == EPI_DUAL) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
         else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
     } else {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
@@ -500,10 +516,16 @@ void launch_bgemm_plain(hipStream_t st, int npad, int nb, const double* A, const
     a.A = A; a.B = Bm; a.C = C; a.npad = npad; a.nbatch = nb;
     launch_bgemm<EPI_PLAIN>(st, a);
 }
-void launch_bgemm_horner(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int coef_base) {
+void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int srcA, int srcB, int dst, int coef_base,
+                       int dst2, int coef_base2) {
     BGemmArgs a{};
-    a.A = w.W[3]; a.B = w.W[src]; a.C = w.W[dst]; a.npad = npad; a.nbatch = nb;
-    a.M1 = w.W[0]; a.M2 = w.W[1]; a.M3 = w.W[2]; a.coef = w.coef; a.coef_base = coef_base;
+    a.A = w.W[srcA]; a.B = w.W[srcB]; a.C = w.W[dst]; a.npad = npad; a.nbatch = nb;
+    a.M1 = w.W[0]; a.M2 = w.W[1]; a.M3 = w.W[2]; a.M4 = w.W[3]; a.coef = w.coef; a.coef_base = coef_base;
+    if (dst2 >= 0) {
+        a.C2 = w.W[dst2]; a.coef_base2 = coef_base2;
+        launch_bgemm<EPI_DUAL>(st, a);
+        return;
+    }
     launch_bgemm<EPI_HORNER>(st, a);
 }
 void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
@@ -642,23 +664,29 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     double beta = fmin(d2v, fmax(d3v, d4v));
     if (!(d2v == d2v) || !(d3v == d3v) || !(d4v == d4v)) beta = __longlong_as_double(0x7ff8000000000000ll);
     atomicMax(w.d2max, dbits(beta));
+    // two-product evaluation of T_16(sigma A) (dto_kernels.h, EXPM2_*): every coefficient carries its power of sigma so
+    // that the kernels work on the unscaled A, A^2, A^3, A^4
     const double sigma = ldexp(1.0, -s);
-    double c = 1.0;
     double* cf = w.coef + (int64_t)b * COEF_STRIDE;
-    for (int i = 0; i <= TAYLOR_M; ++i) {
-        cf[i] = c;
-        c *= sigma / (double)(i + 1);
+    double sp = 1.0;
+    const double s4 = (sigma * sigma) * (sigma * sigma);
+    for (int i = 0; i <= 4; ++i) {
+        cf[COEF_PC + i] = EXPM2_C[i] * sp;
+        cf[COEF_PA + i] = EXPM2_A[i] * sp;
+        cf[COEF_PB + i] = EXPM2_B[i] * sp;
+        cf[COEF_K + i] = EXPM2_K[i] * sp * s4;   // Y = (sigma A)^4 K(sigma A), with A^4 as the left operand
+        sp *= sigma;
     }
 }
 void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w) {
     hipLaunchKernelGGL(k_expm_params, dim3((nb + 63) / 64), dim3(64), 0, st, nb, s_cap, w);
 }
 
-// H3 = c12 I + c13 A + c14 A2 + c15 A3 + c16 A4  (innermost Paterson-Stockmeyer bracket) -> W[5]
+// K = k0 I + k1 A + k2 A2 + k3 A3 + k4 A4  (right factor of Y = A^4 K, scaled coefficients) -> W[5]
 __global__ void __launch_bounds__(256) k_poly_h3(int npad, ChainWork w) {
     const int b = blockIdx.y;
     const int64_t nn = (int64_t)npad * npad;
-    const double* cf = w.coef + (int64_t)b * COEF_STRIDE + 12;
+    const double* cf = w.coef + (int64_t)b * COEF_STRIDE + COEF_K;
     const double c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];
     const double* A1 = w.W[0] + b * nn;
     const double* A2 = w.W[1] + b * nn;
