@@ -181,6 +181,8 @@ struct dto_handle {
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;  // recycled timing events (creating them inside the timed region costs host time)
     int last_smax = 0, last_terms = 0;
+    int expm_form = 0;  // option "expm_form": 0 = by cost, 2 / 3 = forced
+    int last_form = 0;
     std::vector<void*> owned;  // device allocations to free
 
     ~dto_handle();
@@ -585,26 +587,27 @@ void build_basis(dto_handle* h, BilHost& b, int cap) {
 
 void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     const size_t nn = (size_t)b.k.npad * b.k.npad;
-    for (int i = 0; i < 7; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
+    for (int i = 0; i < 9; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
     b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
     b.chain.colsum = own(h, dalloc<double>((size_t)3 * cap * b.k.npad));
     if (!b.d_hump) b.d_hump = own(h, dalloc<unsigned long long>(8));
     b.chain.coef = own(h, dalloc<double>((size_t)cap * COEF_STRIDE));
     b.chain.s = own(h, dalloc<int32_t>(cap));
-    b.chain.smax = own(h, dalloc<int32_t>(4));
-    HIP_CHECK(hipMemset(b.chain.smax, 0, 4 * sizeof(int32_t)));
+    b.chain.s3 = own(h, dalloc<int32_t>(cap));
+    b.chain.smax = own(h, dalloc<int32_t>(8));
+    HIP_CHECK(hipMemset(b.chain.smax, 0, 8 * sizeof(int32_t)));
     b.chain.d2max = reinterpret_cast<unsigned long long*>(b.chain.smax + 2);
     b.chain_cap = cap;
 }
 
 int chunk_size(const dto_handle* h, int npad) {
-    // workspace budget for the 7 chain matrices; DTO_CHAIN_CHUNK overrides
+    // workspace budget for the 9 chain matrices; DTO_CHAIN_CHUNK overrides
     if (const char* e = getenv("DTO_CHAIN_CHUNK")) {
         int v = atoi(e);
         if (v > 0) return v;
     }
-    const double budget = 28e9;
-    int c = (int)(budget / (7.0 * npad * (double)npad * 8.0));
+    const double budget = 36e9;
+    int c = (int)(budget / (9.0 * npad * (double)npad * 8.0));
     c = std::max(8, (c / 8) * 8);
     return (int)std::min<int64_t>(c, std::max<int64_t>(h->P.n_int, 1));
 }
@@ -615,7 +618,7 @@ int chunk_size(const dto_handle* h, int npad) {
 // is then busy with the Taylor products and squarings): the caller uses it to drive the generator sweep on a
 // second stream so that both proceed concurrently.
 double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st,
-                 const std::function<void(double)>& after_last_enqueue = nullptr) {
+                 const std::function<void(double)>& after_last_enqueue = nullptr, const std::function<void()>& in_bubble = nullptr) {
     const int npad = b.k.npad;
     const int64_t nint = h->P.n_int;
     double d2max = 0.0;
@@ -650,17 +653,28 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
         }
         if (!b.use_basis) launch_norm1(st, npad, nb, w);
-        HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
+        HIP_CHECK(hipMemsetAsync(w.smax, 0, 8 * sizeof(int32_t), st));
         launch_expm_params(st, nb, s_ub, w);
         if (c0 == 0) HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
         launch_hump(st, h->P, b.k, dZ, b.d_g1, int0, nb, w.norms, b.d_hump);
-        // the number of squaring launches is data dependent: read back max/sum of s_k (8 bytes) while
-        // the two Taylor products run
+        // the evaluation form and the number of squaring launches are data dependent: read back max/sum of s_k for both
+        // forms (24 bytes); `in_bubble` gives the GPU independent work for the round trip
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
-        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         hipEvent_t ev_s = h->ev_chain;
         HIP_CHECK(hipEventRecord(ev_s, st));
+        if (c0 == 0 && in_bubble) in_bubble();
+        HIP_CHECK(hipEventSynchronize(ev_s));
+        // three products + s3 squarings against two products + s squarings, summed over the chunk; the third product (two
+        // outputs, five epilogue streams: HBM-bound) costs about 1.5 squarings (measured at 256x2000: 1.63 ms against 1.29 ms
+        // per launch, and 2 x 1.50 ms for the two products of the other form)
+        int form = 2 * ((int64_t)hs[1] - (int64_t)hs[5]) > 3 * (int64_t)nb ? 3 : 2;
+        static const int env_form = [] { const char* e = getenv("DTO_EXPM_FORM"); return e ? atoi(e) : 0; }();  // A/B runs
+        if (env_form == 2 || env_form == 3) form = env_form;
+        if (h->expm_form == 2 || h->expm_form == 3) form = h->expm_form;
+        h->last_form = form;
+        launch_expm_coef(st, nb, w, form);
         if (b.use_basis) {
             const int nbpad = ((nb + 127) / 128) * 128;
             launch_basis_coef(st, h->P, b.k, b.basis_all, dZ, int0, nb, nbpad, w.coef);
@@ -669,18 +683,26 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         } else {
             launch_poly_h3(st, npad, nb, w);
         }
-        // Y = A^4 K -> (Y + Pa, Y + Pb) in one launch, then T_16 = (Y + Pa)(Y + Pb) + Pc
+        // Y = A^4 K -> (Y + Pa, Y + Pb) in one launch
         { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 3, 5, 4, COEF_PA, 6, COEF_PB); }
-        { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 4, 6, 5, COEF_PC, -1, 0); }
-        HIP_CHECK(hipEventSynchronize(ev_s));
-        const int s_max = hs[0];
+        if (form == 2) {
+            // T_16 = (Y + Pa)(Y + Pb) + Pc
+            ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb);
+            launch_bgemm_poly(st, npad, nb, w, 4, 6, 5, COEF_PC, -1, 0);
+        } else {
+            // (L, R) = Ya Yb + weights of Ya + polynomials, then r = L R + Pe
+            { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 4, 6, 7, COEF_L, 8, COEF_R, true); }
+            { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 7, 8, 5, COEF_PC, -1, 0); }
+        }
+        const int s_max = form == 3 ? hs[4] : hs[0];
+        const int s_sum = form == 3 ? hs[5] : hs[1];
         read_hump(h, b);  // accumulated over the chunks so far; final after the last one
         {
             double dv;
             memcpy(&dv, hs + 2, sizeof(double));
             d2max = (dv == dv) ? std::max(d2max, dv) : dv;
         }
-        const double sq_flops = s_max > 0 ? gemm_flops * (double)hs[1] / s_max : 0.0;
+        const double sq_flops = s_max > 0 ? gemm_flops * (double)s_sum / s_max : 0.0;
         h->last_smax = std::max(h->last_smax, s_max);
         int src = 5;
         for (int it = 0; it < s_max; ++it) {
@@ -706,7 +728,7 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, boo
         const int nb = (int)std::min<int64_t>(b.chain_cap, nint - c0);
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
-        HIP_CHECK(hipMemsetAsync(w.smax, 0, 4 * sizeof(int32_t), st));
+        HIP_CHECK(hipMemsetAsync(w.smax, 0, 8 * sizeof(int32_t), st));
         launch_fill(st, w.norms, (int64_t)nb * 4, INFINITY);  // norms not computed below stay "unknown" for k_hump
         if (c0 == 0) HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
         if (b.use_basis) {
@@ -854,8 +876,9 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
 void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st) {
     // fill!(∂, 0), evaluator.jl:497 -- the -E_k block of a lone bilinear integrator is skipped: the chain
     // overwrites all of it
-    if (h->bil.size() == 1 && h->P.n_int > 0 && !h->bil[0].small) launch_jac_zero(st, h->P, h->bil[0].k, dvals);
-    else HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
+    // (enqueued inside the chain, where it fills the GPU while the host waits for the scaling decision)
+    const bool lone = h->bil.size() == 1 && h->P.n_int > 0 && !h->bil[0].small;
+    if (!lone) HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
     h->last_terms = 0;
     const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
@@ -887,7 +910,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
-            });
+            }, [&] { if (lone) launch_jac_zero(st, h->P, b.k, dvals); });
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_join, ss));
                 HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1803,6 +1826,11 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
     if (std::string(name) == "reuse_forward_sweep") {
         h->reuse = value != 0;
         for (auto& b : h->bil) b.cache_kind = 0;
+        return 0;
+    }
+    if (std::string(name) == "expm_form") {
+        if (value != 0 && value != 2 && value != 3) return fail(h, "dto_set_option: expm_form takes 0 (by cost), 2 or 3");
+        h->expm_form = (int)value;
         return 0;
     }
     return fail(h, std::string("dto_set_option: unknown option ") + name);

@@ -8,7 +8,7 @@ namespace dto {
 
 constexpr int TAYLOR_M = 16;                 // degree of the matrix Taylor polynomial
 constexpr double THETA_16 = 0.78028743;      // backward-error radius of T_16 in double (Al-Mohy & Higham 2011, Table 3.1 method)
-constexpr int COEF_STRIDE = 20;              // doubles per interval in the coefficient table
+constexpr int COEF_STRIDE = 32;              // doubles per interval in the coefficient table
 // T_16(B) = sum_{r<=16} B^r/r! with TWO products once B..B^4 are known (they come from the generator subspace):
 //   Y = B^4 K(B),   T_16(B) = (Y + Pa(B)) (Y + Pb(B)) + Pc(B),   K, Pa, Pb, Pc of degree <= 4
 // (Paterson-Stockmeyer needs three).  Constants from tools/expm_two_product_coeffs.py: the polynomial identity solved to
@@ -19,6 +19,22 @@ constexpr double EXPM2_K[5] = {0.0021247619694343247, 0.00021337327385069214, 1.
 constexpr double EXPM2_A[5] = {0.15657629060017847, 0.11131927651852432, 0.04459108138499527, 0.00629379053080652, -0.00037523326035530425};
 constexpr double EXPM2_B[5] = {6.392946474783064, 1.8714151425525498, 0.2847453199197648, 0.035205562271892026, 0.0005680709246076226};
 constexpr double EXPM2_C[5] = {-0.000983845027019532, -0.004677417588383601, -0.03797734224052902, 0.005772376398520401, 0.0016659351281941514};
+// THREE products reach order 26 (degree 32): with Ya = Y + Pa, Yb = Y + Pb as above,
+//   Y2 = Ya Yb,   L = Y2 + al Y + Pc,   R = Y2 + be Y + Pd,   r(B) = L R + Pe = exp(B) + O(B^27)
+// Backward-error radius 2.826 against 0.780 for T_16: one product more buys 1.86 squarings, so the engine takes this form
+// whenever the chunk's squaring counts drop by more than one per interval (alpha above ~3.1).  Constants, radius and the
+// rounding check (2.4e-15 at the radius, i.e. what T_16 shows after its two extra squarings) from
+// tools/expm_three_product_coeffs.py.  Table layout: Pe at 0, Pa, Pb, K as above, then the epilogue polynomials of the
+// second product in terms of what that launch can read (Ya, not Y): L = Y2 + al Ya + (Pc - al Pa), R likewise.
+constexpr double THETA_3P = 2.8262;
+constexpr int COEF_L = 20, COEF_R = 26;      // 5 polynomial coefficients + the weight of Ya, each
+constexpr double EXPM3_K[5] = {0.00010356449923003673, 6.187862928353289e-06, 3.070779504073789e-07, -5.446584018061006e-09, 1.6562616286459525e-09};
+constexpr double EXPM3_A[5] = {0.1391656656040143, 0.02356694033215802, 0.01167119890033839, -0.00010096005967499319, 1.5325297016573605e-06};
+constexpr double EXPM3_B[5] = {7.737715512423304, 1.2662945227669398, 0.08360484216486068, 0.006044889884313686, 0.00011349438625758917};
+constexpr double EXPM3_C[5] = {0.555103233975252, 0.12814939510310383, -0.008025777535569014, 0.0024758863835870728, 0.0005738998595941437};
+constexpr double EXPM3_D[5] = {-0.002214174511890132, -0.003623027232609109, 0.00024330997218282246, 0.00631818727802098, 0.0006113923263184991};
+constexpr double EXPM3_E[5] = {-0.7536859320261949, -0.1023057116420999, -0.02122348795960753, 7.744982410724594e-06, 7.128916929996286e-05};
+constexpr double EXPM3_AL = 0.002555902996476596, EXPM3_BE = 3.4021882236587055;
 constexpr int MAX_TYPES = 36;                // column types of a generator sweep (p, d^i, h^{ij})
 constexpr int MAX_DRIVES = 7;
 
@@ -109,12 +125,14 @@ struct SweepTypes {
 
 // ------------------------------------------------------------------ launch wrappers (dto_kernels.hip)
 struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices npad x npad each
-    double* W[7];    // A, A2, A3, A4, then Y+Pa / squaring ping, K / T_16 / squaring pong, Y+Pb
+    double* W[9];    // A, A2, A3, A4, then Y+Pa / squaring ping, K / polynomial / squaring pong, Y+Pb, L, R
     double* norms;   // [C][4]
     double* colsum;  // [3][C][npad] column abs-sums of A^2..A^4 (basis path)
     double* coef;    // [C][COEF_STRIDE]
-    int32_t* s;      // [C] squarings per interval
-    int32_t* smax;   // [0] max, [1] sum of s over the chunk (read back by the host before the squarings)
+    int32_t* s;      // [C] squarings per interval (of the evaluation form in use)
+    int32_t* s3;     // [C] squarings per interval with the three-product form
+    int32_t* smax;   // [0] max, [1] sum of s over the chunk for the two-product form, [4], [5] for the three-product form
+                     // (read back by the host, which then picks the form; [2..3] hold d2max)
     unsigned long long* d2max;  // bit pattern of max_k ||A_k^2||_1^(1/2) over the chunk (exact; plans the sweep)
 };
 
@@ -124,10 +142,13 @@ void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w);
 // 1-norm of matrix `which` only; also folds max_k sqrt(norm) into w.d2max (used when the chain is not run)
 void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int which);
 void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w);
+// coefficient table (and w.s) for the chosen form: 2 = two products (degree 16), 3 = three products (order 26)
+void launch_expm_coef(hipStream_t st, int nb, const ChainWork& w, int form);
 void launch_poly_h3(hipStream_t st, int npad, int nb, const ChainWork& w);
-// W[dst] = W[srcA] W[srcB] + poly(coef_base);  dst2 >= 0: also W[dst2] = W[srcA] W[srcB] + poly(coef_base2)
+// W[dst] = W[srcA] W[srcB] + poly(coef_base);  dst2 >= 0: also W[dst2] = W[srcA] W[srcB] + poly(coef_base2);
+// with_srcA: each polynomial has a sixth coefficient, the weight of W[srcA] itself
 void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int srcA, int srcB, int dst, int coef_base,
-                       int dst2, int coef_base2);
+                       int dst2, int coef_base2, bool with_srcA = false);
 void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
                          const KProb& P, const KBil& B, int64_t int0, double* vals);
 

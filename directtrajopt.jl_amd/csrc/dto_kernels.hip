@@ -317,7 +317,9 @@ void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double*
     hipLaunchKernelGGL(k_build_A, dim3(gx, nb), dim3(256), 0, st, P, B, dZ, int0, A);
 }
 
-enum { EPI_PLAIN = 0, EPI_HORNER = 1, EPI_SQUARE = 2, EPI_DUAL = 3 };  // HORNER: + degree-4 polynomial; DUAL: two such outputs
+enum { EPI_PLAIN = 0, EPI_HORNER = 1, EPI_SQUARE = 2, EPI_DUAL = 3, EPI_DUAL5 = 4 };  // HORNER: + degree-4 polynomial; DUAL: two such outputs; DUAL5: each also + a multiple of M5
+constexpr bool epi_poly(int e) { return e == EPI_HORNER || e == EPI_DUAL || e == EPI_DUAL5; }
+constexpr bool epi_dual(int e) { return e == EPI_DUAL || e == EPI_DUAL5; }
 
 struct BGemmArgs {
     const double* A;
@@ -330,6 +332,7 @@ struct BGemmArgs {
     const double* M2;
     const double* M3;
     const double* M4;
+    const double* M5;   // optional sixth term (the second product adds a multiple of its own left operand)
     const double* coef;
     int coef_base, coef_base2;
     double* C2;
@@ -397,17 +400,18 @@ k_bgemm(BGemmArgs a) {
         }
 
         double* Cb = a.C + b * nn;
-        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
-        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr;
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr, *M5 = nullptr;
         double* Cb2 = nullptr;
-        if (EPI == EPI_HORNER || EPI == EPI_DUAL) {
+        if (epi_poly(EPI)) {
             const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
             c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
             M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn; M4 = a.M4 + b * nn;
-            if (EPI == EPI_DUAL) {
+            if (epi_dual(EPI)) {
                 const double* ef = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base2;
                 e0 = ef[0]; e1 = ef[1]; e2 = ef[2]; e3 = ef[3]; e4 = ef[4];
                 Cb2 = a.C2 + b * nn;
+                if (EPI == EPI_DUAL5) { M5 = a.M5 + b * nn; c5 = cf[5]; e5 = ef[5]; }
             }
         }
 #pragma unroll
@@ -420,11 +424,17 @@ k_bgemm(BGemmArgs a) {
                     const int row = row0 + 16 * ti;
                     const int64_t off = (int64_t)col * a.npad + row;
                     double v2 = acc.v[ti][tj][r];
-                    if (EPI == EPI_HORNER || EPI == EPI_DUAL) {
+                    if (epi_poly(EPI)) {
                         const double m1 = __builtin_nontemporal_load(&M1[off]), m2 = __builtin_nontemporal_load(&M2[off]),
                                      m3 = __builtin_nontemporal_load(&M3[off]), m4 = M4[off];  // M4 is also this launch's A operand
-                        if (EPI == EPI_DUAL) {
-                            double w2 = v2 + (e1 * m1 + e2 * m2 + e3 * m3 + e4 * m4);
+                        if (epi_dual(EPI)) {
+                            double w2 = v2;
+                            if (EPI == EPI_DUAL5) {
+                                const double m5 = M5[off];  // this launch's A operand
+                                w2 += e5 * m5;
+                                v2 += c5 * m5;
+                            }
+                            w2 += e1 * m1 + e2 * m2 + e3 * m3 + e4 * m4;
                             if (row == col) w2 += e0;
                             __builtin_nontemporal_store(w2, &Cb2[off]);
                         }
@@ -433,7 +443,7 @@ k_bgemm(BGemmArgs a) {
                     }
                     __builtin_nontemporal_store(v2, &Cb[off]);  // 1 GB per launch: gone from L2 before its reader starts
                 }
-                if (EPI == EPI_DUAL) __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later columns from piling up (spills)
+                if (epi_dual(EPI)) __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later columns from piling up (spills)
             }
     }
 }
@@ -459,12 +469,12 @@ template <class Cfg, int EPI>
 static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_cu) {
     int grid = batch_tile_count(a.nbatch, (a.npad / Cfg::TM) * (a.npad / Cfg::TN));
     int wgs = bgemm_wgs_choice();
-    if (wgs < 0) wgs = (EPI == EPI_HORNER || EPI == EPI_DUAL) ? 0 : wgs_per_cu;
+    if (wgs < 0) wgs = epi_poly(EPI) ? 0 : wgs_per_cu;
     else if (wgs > 0) wgs = wgs_per_cu;
     if (wgs > 0 && grid > wgs * 256) grid = wgs * 256;
     if constexpr (Cfg::TM == 128 && Cfg::TN == 128 && Cfg::KB == 16) {
         int dma = bgemm_dma_choice();
-        if (dma < 0) dma = (EPI == EPI_HORNER || EPI == EPI_DUAL) ? 0 : 1;
+        if (dma < 0) dma = epi_poly(EPI) ? 0 : 1;
         if (dma) {
             hipLaunchKernelGGL((k_bgemm<Cfg, EPI, true>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
             return;
@@ -499,12 +509,12 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
             default:
                 // measured in the engine (256x2000): the fused-polynomial epilogue hides better behind 8 waves,
                 // the plain / squaring products run faster with 4 waves of 64x64
-                if (EPI == EPI_HORNER || EPI == EPI_DUAL) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+                if (epi_poly(EPI)) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
                 else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
                 return;
         }
     } else if (a.npad % 128 == 0) {
-        if (EPI == EPI_HORNER || EPI == EPI_DUAL) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+        if (epi_poly(EPI)) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
         else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
     } else {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
@@ -517,12 +527,17 @@ void launch_bgemm_plain(hipStream_t st, int npad, int nb, const double* A, const
     launch_bgemm<EPI_PLAIN>(st, a);
 }
 void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int srcA, int srcB, int dst, int coef_base,
-                       int dst2, int coef_base2) {
+                       int dst2, int coef_base2, bool with_srcA) {
     BGemmArgs a{};
     a.A = w.W[srcA]; a.B = w.W[srcB]; a.C = w.W[dst]; a.npad = npad; a.nbatch = nb;
     a.M1 = w.W[0]; a.M2 = w.W[1]; a.M3 = w.W[2]; a.M4 = w.W[3]; a.coef = w.coef; a.coef_base = coef_base;
     if (dst2 >= 0) {
         a.C2 = w.W[dst2]; a.coef_base2 = coef_base2;
+        if (with_srcA) {
+            a.M5 = w.W[srcA];
+            launch_bgemm<EPI_DUAL5>(st, a);
+            return;
+        }
         launch_bgemm<EPI_DUAL>(st, a);
         return;
     }
@@ -638,9 +653,9 @@ void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int 
     hipLaunchKernelGGL(k_norm1, dim3(nb, 1), dim3(256), 0, st, npad, w, which);
 }
 
-// Scaling parameter s_k and the scaled Taylor coefficients sigma^i / i!  (sigma = 2^-s_k).
+// Scaling parameter s_k for both evaluation forms of the polynomial (sigma = 2^-s_k).
 // alpha_p(A) = max(||A^p||^(1/p), ||A^(p+1)||^(1/(p+1))) bounds the truncation series for
-// p(p-1) <= m+1 (Al-Mohy & Higham 2009, Thm 4.2); s_k = ceil(log2(alpha / theta_16)), at least 1 so
+// p(p-1) <= m+1 (Al-Mohy & Higham 2009, Thm 4.2); s_k = ceil(log2(alpha / theta)), at least 1 so
 // that the last product of the chain is always a squaring (the one that stores into the Jacobian).
 __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,23 +675,53 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     w.s[b] = s;
     atomicMax(&w.smax[0], s);
     atomicAdd(&w.smax[1], s);
+    int s3 = 1;
+    if (alpha > THETA_3P) {
+        s3 = (int)ceil(log2(alpha / THETA_3P));
+        if (s3 < 1) s3 = 1;
+    }
+    if (s3 > s_cap) s3 = s_cap;
+    if (!(alpha == alpha)) s3 = 1;
+    w.s3[b] = s3;
+    atomicMax(&w.smax[4], s3);
+    atomicAdd(&w.smax[5], s3);
     // growth rate handed to the sweep planner: ||A^t|| <= d2^t (t even) and <= max(d3,d4)^t (t >= 6)
     double beta = fmin(d2v, fmax(d3v, d4v));
     if (!(d2v == d2v) || !(d3v == d3v) || !(d4v == d4v)) beta = __longlong_as_double(0x7ff8000000000000ll);
     atomicMax(w.d2max, dbits(beta));
-    // two-product evaluation of T_16(sigma A) (dto_kernels.h, EXPM2_*): every coefficient carries its power of sigma so
-    // that the kernels work on the unscaled A, A^2, A^3, A^4
+}
+// Coefficient table of the chosen evaluation form (dto_kernels.h, EXPM2_* / EXPM3_*): every coefficient carries its power
+// of sigma = 2^-s so that the kernels work on the unscaled A, A^2, A^3, A^4.
+__global__ void k_expm_coef(int nb, ChainWork w, int form) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    int s = w.s[b];
+    if (form == 3) { s = w.s3[b]; w.s[b] = s; }
     const double sigma = ldexp(1.0, -s);
     double* cf = w.coef + (int64_t)b * COEF_STRIDE;
     double sp = 1.0;
     const double s4 = (sigma * sigma) * (sigma * sigma);
     for (int i = 0; i <= 4; ++i) {
-        cf[COEF_PC + i] = EXPM2_C[i] * sp;
-        cf[COEF_PA + i] = EXPM2_A[i] * sp;
-        cf[COEF_PB + i] = EXPM2_B[i] * sp;
-        cf[COEF_K + i] = EXPM2_K[i] * sp * s4;   // Y = (sigma A)^4 K(sigma A), with A^4 as the left operand
+        if (form == 3) {
+            cf[COEF_PC + i] = EXPM3_E[i] * sp;
+            cf[COEF_PA + i] = EXPM3_A[i] * sp;
+            cf[COEF_PB + i] = EXPM3_B[i] * sp;
+            cf[COEF_K + i] = EXPM3_K[i] * sp * s4;
+            cf[COEF_L + i] = (EXPM3_C[i] - EXPM3_AL * EXPM3_A[i]) * sp;
+            cf[COEF_R + i] = (EXPM3_D[i] - EXPM3_BE * EXPM3_A[i]) * sp;
+        } else {
+            cf[COEF_PC + i] = EXPM2_C[i] * sp;
+            cf[COEF_PA + i] = EXPM2_A[i] * sp;
+            cf[COEF_PB + i] = EXPM2_B[i] * sp;
+            cf[COEF_K + i] = EXPM2_K[i] * sp * s4;   // Y = (sigma A)^4 K(sigma A), with A^4 as the left operand
+        }
         sp *= sigma;
     }
+    cf[COEF_L + 5] = EXPM3_AL;
+    cf[COEF_R + 5] = EXPM3_BE;
+}
+void launch_expm_coef(hipStream_t st, int nb, const ChainWork& w, int form) {
+    hipLaunchKernelGGL(k_expm_coef, dim3((nb + 63) / 64), dim3(64), 0, st, nb, w, form);
 }
 void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w) {
     hipLaunchKernelGGL(k_expm_params, dim3((nb + 63) / 64), dim3(64), 0, st, nb, s_cap, w);

@@ -171,6 +171,35 @@ def test_large_state_shapes_against_the_oracle(n, m, N):
     _check(O.make_scaled_problem(N, n, m, seed=11), tag=f"large-state n={n}")
 
 
+@pytest.mark.parametrize("n,m", [(64, 4), (128, 2)])
+def test_both_polynomial_forms_of_the_matrix_exponential(n, m):
+    """Option "expm_form": the two-product degree-16 form (radius 0.78) and the three-product order-26 form (radius 2.83) of
+    the propagator chain are each checked against the oracle on the same point (alpha ~ 4.5: 3 squarings against 1), and
+    against each other; n = 64 takes the plain power chain, n = 128 the generator-subspace powers."""
+    import dto_amd
+    p = O.make_scaled_problem(4, n, m, seed=3)
+    Z = p.Z0.copy()
+    Z[p.dt_idx::p.z] = 0.1 * np.sqrt(256.0 / n) * 1.1
+    ref = O.OracleEvaluator(p).eval_constraint_jacobian(Z)
+    ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)
+    try:
+        got, squarings = {}, {}
+        for form in (2, 3, 0):
+            ev.set_option("expm_form", form)
+            got[form] = np.full(ev.shard.jac_len, np.nan)
+            ev.eval_constraint_jacobian(got[form], Z)
+            squarings[form] = ev.last_stats()[0]
+            assert rel_err(got[form], ref) <= TOL, (form, rel_err(got[form], ref))
+        print("squarings", squarings, "form 2 vs 3", rel_err(got[2], got[3]))
+        assert squarings[3] < squarings[2]
+        assert rel_err(got[2], got[3]) <= 1e-12
+        assert np.array_equal(got[0], got[3])  # by cost: three products + 1 squaring beat two products + 3
+        with pytest.raises(Exception):
+            ev.set_option("expm_form", 4)
+    finally:
+        ev.close()
+
+
 def test_external_integrator_merged_from_host_blocks():
     """an integrator evaluated outside the engine (the shape TimeDependentBilinearIntegrator has:
     both knot halves of the Jacobian block, cross part of the Hessian block) placed between built-in integrators."""
