@@ -425,8 +425,10 @@ k_bgemm(BGemmArgs a) {
                     const int64_t off = (int64_t)col * a.npad + row;
                     double v2 = acc.v[ti][tj][r];
                     if (epi_poly(EPI)) {
+                        // the second product of the three-product form has no A^4 term (EXPM3_*[4] = 0); in the first product of
+                        // either form M4 is the launch's own A operand (L2-hot)
                         const double m1 = __builtin_nontemporal_load(&M1[off]), m2 = __builtin_nontemporal_load(&M2[off]),
-                                     m3 = __builtin_nontemporal_load(&M3[off]), m4 = M4[off];  // M4 is also this launch's A operand
+                                     m3 = __builtin_nontemporal_load(&M3[off]), m4 = EPI == EPI_DUAL5 ? 0.0 : M4[off];
                         if (epi_dual(EPI)) {
                             double w2 = v2;
                             if (EPI == EPI_DUAL5) {

@@ -236,7 +236,7 @@ int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const do
  *   callback is timed cold). */
 /*   "expm_form" (default 0): evaluation form of the matrix-exponential polynomial in eval_constraint_jacobian.  0 picks per
  *   call by cost: two products for the degree-16 Taylor polynomial (backward-error radius 0.78) or three products for an
- *   order-26 approximant (radius 2.83, i.e. up to two squarings fewer); 2 / 3 force one form (tests, measurements). */
+ *   order-26 approximant (radius 2.82, i.e. up to two squarings fewer); 2 / 3 force one form (tests, measurements). */
 int dto_set_option(dto_handle* h, const char* name, int64_t value);
 
 /* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */

@@ -173,7 +173,7 @@ def test_large_state_shapes_against_the_oracle(n, m, N):
 
 @pytest.mark.parametrize("n,m", [(64, 4), (128, 2)])
 def test_both_polynomial_forms_of_the_matrix_exponential(n, m):
-    """Option "expm_form": the two-product degree-16 form (radius 0.78) and the three-product order-26 form (radius 2.83) of
+    """Option "expm_form": the two-product degree-16 form (radius 0.78) and the three-product order-26 form (radius 2.82) of
     the propagator chain are each checked against the oracle on the same point (alpha ~ 4.5: 3 squarings against 1), and
     against each other; n = 64 takes the plain power chain, n = 128 the generator-subspace powers."""
     import dto_amd

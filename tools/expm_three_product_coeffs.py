@@ -13,7 +13,10 @@ computation of the matrix exponential", 2019: orders 15+/21+/24+/30+ with 3..5 p
 
 How the constants were found: Gauss-Newton (minimum-norm steps, relative scaling) in float64 from random perturbations of
 the two-product solution evaluated at B/2 (so that L ~ R ~ exp(B/2)); for order 24 five of 24 starts converge, for order 26
-one of 32 (START below), for orders 27 and 28 none of 128.  This script polishes START in 60-digit arithmetic (residual
+one of 32, for orders 27 and 28 none of 128.  Of the five free parameters left at order 26, three were then driven to zero
+by continuation (a4 by the gauge k0 <-> a4, b4, c4, d4; c4 and d4 so that the HBM-bound second product streams one matrix
+less; e3 = e4 = 0 is out of reach: the system is singular there) -- START below.  This script polishes START in 60-digit
+arithmetic with those three held at zero (residual
 < 1e-50 on the r!-scaled coefficients), computes the backward-error radius theta exactly as for Taylor polynomials
 (Al-Mohy & Higham 2009/2011: h(x) = log(e^-x r(x)) = sum_{k>26} h_k x^k, theta = max{t : sum |h_k| t^(k-1) <= 2^-53}; the
 same routine gives 0.78028743 for T_16), measures the rounding error of the evaluation in double and prints the constants."""
@@ -21,13 +24,14 @@ import mpmath as mp
 import numpy as np
 
 P_ORDER = 26
-START = [0.00010356449923003673, 6.187862928353289e-06, 3.070779504073789e-07, -5.446584018061006e-09, 1.6562616286459525e-09,
-         0.1391656656040143, 0.02356694033215802, 0.01167119890033839, -0.00010096005967499319, 1.5325297016573605e-06,
-         7.737715512423304, 1.2662945227669398, 0.08360484216486068, 0.006044889884313686, 0.00011349438625758917,
-         0.002555902996476596, 3.4021882236587055,
-         0.555103233975252, 0.12814939510310383, -0.008025777535569014, 0.0024758863835870728, 0.0005738998595941437,
-         -0.002214174511890132, -0.003623027232609109, 0.00024330997218282246, 0.00631818727802098, 0.0006113923263184991,
-         -0.7536859320261949, -0.1023057116420999, -0.02122348795960753, 7.744982410724594e-06, 7.128916929996286e-05]
+START = [0.00010379876595047617, 6.073095185901804e-06, 3.1522969877676845e-07, -5.57963065580417e-09, 1.6549758371825144e-09,
+         0.06925346208946212, 0.1399878337730723, 0.008815043145043342, -1.5454750321185654e-05, 0.0,
+         7.864692916335445, 1.1432871789700823, 0.08599260924787294, 0.006001949142362251, 0.000114009585419753,
+         0.009959087291030108, 3.6322128429901483,
+         1.4279329585415197, -0.648965244154349, -0.10937992097592901, -0.0031202517331481694, 0.0,
+         0.0035917931833685884, -0.8738586720421705, -0.10354040058330033, 0.0006117561678190711, 0.0,
+         -0.0814706004657684, 0.10462167443095102, 0.008296003021444887, 0.0020999533880951024, 0.00010675255813813872]
+ZERO = (9, 21, 26)  # a4 = c4 = d4 = 0: the second product's epilogue does not read A^4
 
 
 def pmul(p, q):
@@ -64,23 +68,26 @@ def residual(v):
 
 
 def polish(v0):
-    v = mp.matrix([mp.mpf(x) for x in v0])
+    v = [mp.mpf(x) for x in v0]
+    free = [j for j in range(32) if j not in ZERO]
     for _ in range(12):
-        f0 = residual(list(v))
+        f0 = residual(v)
         if max(abs(x) for x in f0) < mp.mpf(10) ** -50:
             break
-        J = mp.matrix(len(f0), 32)
-        for j in range(32):
+        J = mp.matrix(len(f0), len(free))
+        for c, j in enumerate(free):
             dl = mp.mpf(10) ** -30 * max(abs(v[j]), mp.mpf(10) ** -12)
             w = list(v)
             w[j] += dl
             f1 = residual(w)
             for i in range(len(f0)):
-                J[i, j] = (f1[i] - f0[i]) / dl
-        D = mp.diag([max(abs(v[j]), mp.mpf(10) ** -9) for j in range(32)])
+                J[i, c] = (f1[i] - f0[i]) / dl
+        D = mp.diag([max(abs(v[j]), mp.mpf(10) ** -9) for j in free])
         Js = J * D
-        v = v - D * (Js.T * mp.lu_solve(Js * Js.T, mp.matrix(f0)))
-    assert max(abs(x) for x in residual(list(v))) < mp.mpf(10) ** -50
+        step = D * (Js.T * mp.lu_solve(Js * Js.T, mp.matrix(f0)))
+        for c, j in enumerate(free):
+            v[j] -= step[c]
+    assert max(abs(x) for x in residual(v)) < mp.mpf(10) ** -50
     return v
 
 
