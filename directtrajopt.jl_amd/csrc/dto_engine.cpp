@@ -453,10 +453,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
               bool skip_init = false) {
     const double flops_step = [&] {
         double segs = 0;
-        for (int t = 0; t < ty.T; ++t) {
-            segs += b.k.m + 1;
-            segs += ty.t[t].n_extra;
-        }
+        for (int t = 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
         return 2.0 * b.k.npad * (double)b.k.npad * w.Kpad * segs;
     }();
     const size_t tstride = (size_t)ty.T * w.Kpad * w.npad;

@@ -62,11 +62,15 @@ using GemmAcc = GemmAccS<GemmCfg<TM, TN>>;
 //   B      : pointer to row 0 of the K range, the tile's first column (column-major, ldb)
 //   colscale : nullptr, or TN per-column factors applied to B (b[k][n] *= colscale[n])
 //   Klen   : multiple of KB
+//   TWO    : the staged operand is colscale .* B + colscale2 .* B2 (same shape and ldb): two products with the same left
+//            operand for the price of one (the sweep's G_j (c_j d^j) + G_j (dt p))
 // All threads of the workgroup must call it; it ends with a barrier so LDS may be reused immediately.
-template <class C>
+template <class C, bool TWO = false>
 __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double* __restrict__ A, int lda,
                                                   const double* __restrict__ B, int ldb, int Klen,
-                                                  const double* __restrict__ colscale, double* smem) {
+                                                  const double* __restrict__ colscale, double* smem,
+                                                  const double* __restrict__ B2 = nullptr,
+                                                  const double* __restrict__ colscale2 = nullptr) {
     constexpr int TM = C::TM, TN = C::TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,9 +81,9 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
     double* As = smem;
     double* Bs = smem + 2 * C::AS_ELEMS;
 
-    d2 ra[C::A_LD], rb[C::B_LD];
+    d2 ra[C::A_LD], rb[C::B_LD], rb2[TWO ? C::B_LD : 1];
     int a_k[C::A_LD], a_m[C::A_LD], b_n[C::B_LD], b_k[C::B_LD];
-    double bsc[C::B_LD];
+    double bsc[C::B_LD], bsc2[TWO ? C::B_LD : 1];
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
         const int idx = tid + C::THREADS * i;
@@ -92,6 +96,7 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
         b_n[i] = idx / (C::KB / 2);
         b_k[i] = 2 * (idx % (C::KB / 2));
         bsc[i] = colscale ? colscale[b_n[i]] : 1.0;
+        if constexpr (TWO) bsc2[i] = colscale2[b_n[i]];
     }
 
     const int nkb = Klen / C::KB;
@@ -102,8 +107,10 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
         for (int i = 0; i < C::A_LD; ++i)
             ra[i] = *reinterpret_cast<const d2*>(A + (size_t)(k0 + a_k[i]) * lda + a_m[i]);
 #pragma unroll
-        for (int i = 0; i < C::B_LD; ++i)
+        for (int i = 0; i < C::B_LD; ++i) {
             rb[i] = *reinterpret_cast<const d2*>(B + (size_t)b_n[i] * ldb + k0 + b_k[i]);
+            if constexpr (TWO) rb2[i] = *reinterpret_cast<const d2*>(B2 + (size_t)b_n[i] * ldb + k0 + b_k[i]);
+        }
     };
     auto store_panel = [&](int buf) {
         double* as = As + buf * C::AS_ELEMS;
@@ -116,6 +123,10 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
             d2 v = rb[i];
             v.x *= bsc[i];
             v.y *= bsc[i];
+            if constexpr (TWO) {
+                v.x += bsc2[i] * rb2[i].x;
+                v.y += bsc2[i] * rb2[i].y;
+            }
             *reinterpret_cast<d2*>(bs + b_n[i] * C::LDB_S + b_k[i]) = v;
         }
     };
@@ -222,6 +233,13 @@ __device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const doub
                                                 const double* __restrict__ B, int ldb, int Klen,
                                                 const double* __restrict__ colscale, double* smem) {
     gemm_accumulate_s<GemmCfg<TM, TN>>(acc, A, lda, B, ldb, Klen, colscale, smem);
+}
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_accumulate2(GemmAcc<TM, TN>& acc, const double* __restrict__ A, int lda,
+                                                 const double* __restrict__ B, int ldb, int Klen,
+                                                 const double* __restrict__ colscale, const double* __restrict__ B2,
+                                                 const double* __restrict__ colscale2, double* smem) {
+    gemm_accumulate_s<GemmCfg<TM, TN>, true>(acc, A, lda, B, ldb, Klen, colscale, smem, B2, colscale2);
 }
 
 // Coordinates of the calling lane's accumulator elements inside the TM x TN tile.

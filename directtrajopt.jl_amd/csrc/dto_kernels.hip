@@ -935,7 +935,8 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs& a, GemmAcc<TM, T
 // One Taylor step of the sweep for every owned interval at once:
 //   term_{t+1}[type] = 1/(t+1) * ( sum_j G_j * (term_t[type] .* dt ubar_j/q)  +  sum_extra G_g * (term_t[src] .* dt/q * mult) )
 // i.e. a GEMM whose K dimension is the concatenation of the generator blocks, the per-interval
-// bilinear coefficients being applied to the B panel while it is staged into LDS.
+// bilinear coefficients being applied to the B panel while it is staged into LDS; an extra term shares the
+// segment of its generator (both right-hand sides are combined in the staging registers).
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(SweepArgs a) {
     using Cfg = GemmCfg<TM, TN>;
@@ -954,15 +955,24 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
     acc.zero();
     if (a.mode == 0) {
         const double* Bt = a.Zin + ty * typesz + (int64_t)ct * TN * npad;
-        for (int j = 0; j <= m; ++j)
-            gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, Bt, npad, npad,
-                                    a.w.scaleA + (int64_t)j * Kpad + ct * TN, smem);
         const TypeDesc td = a.ty.t[ty];
-        for (int e = 0; e < td.n_extra; ++e) {
-            const double* Bs = a.Zin + td.src[e] * typesz + (int64_t)ct * TN * npad;
-            // scaleE[0] carries dt/q, scaleE[1] carries 2 dt/q (the i == j second-order terms)
-            gemm_accumulate<TM, TN>(acc, a.G + (int64_t)td.gen[e] * nn + (int64_t)rt * TM, npad, Bs, npad, npad,
-                                    a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
+        // an extra term G_g (dt term_t[src]) rides in generator g's own segment: G_g (c_g term_t[type] + dt term_t[src]) --
+        // the two operands are added while the panel is staged, the product is paid once (the extras of one type name
+        // distinct generators: make_types)
+        for (int j = 0; j <= m; ++j) {
+            int e = -1;
+            for (int x = 0; x < td.n_extra; ++x)
+                if (td.gen[x] == j) e = x;
+            if (e >= 0) {
+                const double* Bs = a.Zin + td.src[e] * typesz + (int64_t)ct * TN * npad;
+                // scaleE[0] carries dt/q, scaleE[1] carries 2 dt/q (the i == j second-order terms)
+                gemm_accumulate2<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, Bt, npad, npad,
+                                         a.w.scaleA + (int64_t)j * Kpad + ct * TN, Bs,
+                                         a.w.scaleE + (td.mult[e] == 2.0 ? Kpad : 0) + ct * TN, smem);
+            } else {
+                gemm_accumulate<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, Bt, npad, npad,
+                                        a.w.scaleA + (int64_t)j * Kpad + ct * TN, smem);
+            }
         }
     } else if (a.mode == 3) {
         gemm_accumulate<TM, TN>(acc, a.G + ty * nn + (int64_t)rt * TM, npad, a.V + (int64_t)ct * TN * npad, npad, npad,
