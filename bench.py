@@ -175,6 +175,14 @@ def main():
         ms_v, n_v, fl_v = ev.profile_get(nm)
         if n_v:
             variants[key] = {"launches": n_v, "avg_launch_ms": ms_v / n_v, "tflops": fl_v / (ms_v * 1e-3) / 1e12}
+            # the polynomial products ("horner") also sit on the HBM roof: per launch two operands, three or four power
+            # matrices in the epilogue and one or two outputs -- seven npad x npad matrices per interval in each of the
+            # three launches of the order-26 form; a squaring moves two
+            streams = {"horner": 7, "square": 2}.get(key)
+            if streams and (n, Nk) == (256, 2000):
+                gbs = streams * 8.0 * n * n * (Nk - 1) / (ms_v / n_v * 1e-3) / 1e9
+                variants[key].update({"algorithmic_hbm_bytes": streams * 8.0 * n * n * (Nk - 1), "hbm_gbs": gbs,
+                                      "hbm_frac": gbs / HBM_PEAK_GBS})
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
 
