@@ -349,7 +349,7 @@ int64_t hess_block_start(const dto_handle* h, int64_t kn) {
 // sweeps and chain
 // ------------------------------------------------------------------------------------------
 
-void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool adjoint) {
+void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool with_W) {
     const int npad = b.k.npad;
     w.npad = npad;
     w.T_alloc = T;
@@ -361,7 +361,7 @@ void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool adjoint) {
     w.Z[1] = own(h, dalloc<double>(typesz * T));
     w.S = own(h, dalloc<double>(typesz * T));
     w.GY = own(h, dalloc<double>(typesz));
-    w.W = adjoint ? own(h, dalloc<double>(typesz * (b.k.m + 1))) : nullptr;
+    w.W = with_W ? own(h, dalloc<double>(typesz * (b.k.m + 1))) : nullptr;
     w.scaleA = own(h, dalloc<double>((size_t)(b.k.m + 1) * w.Kpad));
     w.scaleU = own(h, dalloc<double>((size_t)(b.k.m + 1) * w.Kpad));
     w.scaleE = own(h, dalloc<double>((size_t)2 * w.Kpad));
@@ -473,7 +473,9 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
                 if (store) {
                     ws.Z[0] = w.Zt + (size_t)t * tstride;
                     ws.Z[1] = w.Zt + (size_t)(t + 1) * tstride;
-                    launch_sweep_step(st, b.k, ws, ty, transposed, t, 0);
+                    // one stored type: split K over the generators, the next terms' slots are the scratch
+                    const bool split = ty.T == 1 && (int64_t)(t + b.k.m + 4) <= (int64_t)w.dcap * (1 + b.k.m);
+                    launch_sweep_step(st, b.k, ws, ty, transposed, t, 0, split ? 1 : 0);
                 } else {
                     launch_sweep_step(st, b.k, w, ty, transposed, t, buf);
                 }
@@ -938,36 +940,44 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             }
             SweepPlan plan = plan_from(h, b, dZ, st);
             const bool pair = b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
-            SweepTypes ty2 = make_types(b.k.m, !pair);
-            int steps_f;
-            if (pair && same && b.cache_kind == 3) {
-                steps_f = b.cache_steps;  // forward terms, sums and G(u)y of this very point are still in b.fw
+            const int m = b.k.m, T1 = 1 + m;
+            int steps_f, Tf = T1;  // Tf: types per stored forward term
+            if (pair) {
+                // Pairing path: every tangent comes from the ADJOINT sweep (the (x,u) block needs those anyway); of the forward
+                // sweep only the Taylor terms of the p column are used (k_hess_pair, k_hess_bilinear).
+                if (same && b.cache_kind == 3) {
+                    steps_f = b.cache_steps;  // the Jacobian of this very point stored every forward term
+                } else {
+                    Tf = 1;
+                    steps_f = run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, plan, st, true);
+                    b.cache_kind = h->reuse ? 1 : 0;  // the p sums are valid, the tangent sums are not
+                    b.cache_steps = steps_f;
+                }
+                launch_apply_generators(st, b.k, b.fw, 0, b.fw.Zt, b.fw.W);  // V_l = G_l x (term 0 of the p column is x)
             } else {
-                steps_f = run_sweep(h, b, b.fw, ty2, dZ, nullptr, 0, 0, plan, st, pair);
+                steps_f = run_sweep(h, b, b.fw, make_types(m, true), dZ, nullptr, 0, 0, plan, st, false);
                 launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
-                b.cache_kind = (h->reuse && pair) ? 3 : 0;
-                b.cache_steps = steps_f;
+                b.cache_kind = 0;
+                // W_j = G_j' mu from the adjoint sweep's term-0 buffer
+                launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
+                launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
             }
-            // W_j = G_j' mu from the adjoint sweep's term-0 buffer, then the adjoint sweep itself
-            launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
-            launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
-            SweepTypes ty1 = make_types(b.k.m, false);
+            SweepTypes ty1 = make_types(m, false);
             const int steps_a = run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair);
             launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
             launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
             if (pair) {
-                // (u_i,u_j) block from the stored Taylor terms of the two first-order sweeps (no second-order
-                // columns): Beta-weighted sums U_a of the adjoint p terms, G_j' U_a, then dot products with the
-                // forward tangent terms
-                const int nf = steps_f + 1, na = steps_a + 1, T1 = 1 + b.k.m, m = b.k.m;
+                // (u_i,u_j) block from the stored Taylor terms (no second-order columns): Beta-weighted sums U_a of the
+                // forward p terms, G_j U_a, then dot products with the adjoint tangent terms
+                const int nf = steps_f + 1, na = steps_a + 1;
                 const int64_t typesz = (int64_t)b.fw.Kpad * b.k.npad;
-                const int64_t cols = (int64_t)nf * b.fw.Kpad;  // one type of every stored term
-                launch_pair_combine(st, b.ad, T1, 1, nf, na, b.fw.nterms, b.d_Btab, b.Upair);
+                const int64_t cols = (int64_t)na * b.fw.Kpad;  // one type of every stored term
+                launch_pair_combine(st, b.fw, Tf, 1, na, nf, b.ad.nterms, b.d_Btab, b.Upair);
                 {
                     ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m);
-                    launch_apply_generators_cols(st, b.k, b.fw, 1, b.Upair, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)T1 * typesz);
+                    launch_apply_generators_cols(st, b.k, b.fw, 0, b.Upair, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)Tf * typesz);
                 }
-                launch_hess_pair(st, h->P, b.k, b.fw, nf, b.EP, dH);
+                launch_hess_pair(st, h->P, b.k, b.ad, na, b.EP, dH);
             }
         } else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) {
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
@@ -1473,7 +1483,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             }
             const int T_fw = std::max(2 + m, d->eval_hessian ? 1 + m + m * (m + 1) / 2 : 1 + m);  // +1: exp(A)w_x column of J w
             if (T_fw > MAX_TYPES) throw HipError{"bilinear integrator: too many drives for the second-order sweep"};
-            alloc_sweep(h, b, b.fw, T_fw, false);
+            alloc_sweep(h, b, b.fw, T_fw, d->eval_hessian != 0);  // W: G_l x for the Hessian's scalar blocks
             if (d->eval_hessian) {
                 alloc_sweep(h, b, b.ad, 1 + m, true);
                 // pairing path: term stores for both sweeps + E_j*terms + Beta-weighted sums (skipped when they

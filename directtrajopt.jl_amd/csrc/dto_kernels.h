@@ -188,7 +188,7 @@ void launch_jtv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const Sw
 void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const double* dZ, const double* w, double* y, int transpose);
 
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
-                       int t, int in_buf);
+                       int t, int in_buf, int split_store = 0);
 void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);
 // out[j] = G_j (or G_j') * V for every generator j (no summation): out [(m+1)][Kpad][npad]
 void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,

@@ -1068,14 +1068,15 @@ __global__ void __launch_bounds__(256) k_sweep_finalize(SweepBuf w, double* __re
 }
 
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed, int t,
-                       int in_buf) {
+                       int in_buf, int split_store) {
     SweepArgs a{};
     a.B = B; a.w = w; a.ty = ty; a.G = transposed ? B.GT : B.G;
     a.Zin = w.Z[in_buf]; a.Zout = w.Z[in_buf ^ 1]; a.t = t; a.mode = 0;
     // a single column type (eval_constraint) offers few tiles with a long K loop each: split K by generator into the
     // unused type slots of the output buffer, then sum the partials (DTO_SWEEP_SPLITK=0 disables)
     static const bool splitk = [] { const char* e = getenv("DTO_SWEEP_SPLITK"); return !e || atoi(e) != 0; }();
-    if (splitk && ty.T == 1 && B.m >= 1 && w.T_alloc >= B.m + 2 && w.Z[0] != w.Zt && a.Zin != w.Zt) {
+    // (store mode with one type: the slots of the NEXT m+1 terms serve as scratch -- the caller vouches for the room)
+    if (splitk && ty.T == 1 && B.m >= 1 && (split_store || (w.T_alloc >= B.m + 2 && w.Z[0] != w.Zt && a.Zin != w.Zt))) {
         const int64_t typesz = (int64_t)w.Kpad * w.npad;
         a.mode = 3; a.V = a.Zin; a.out = a.Zout + typesz;
         launch_sweep_kernel(st, a, B.m + 1);
@@ -1138,13 +1139,16 @@ void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int n_types,
                        nterms_f, Btab, U);
 }
 
-// (u_i, u_j) block of mu_k' f by the pairing formula.  With p_a, d^i_a the Taylor terms of the forward sweep
-// (exp(A)x and its u_i-tangent) and pt_b those of exp(A')mu,
+// (u_i, u_j) block of mu_k' f by the pairing formula.  With p_a, d^i_a the Taylor terms of ONE sweep with tangents
+// (exp(A)x and its u_i-tangent) and pt_b the plain terms of the OTHER sweep (exp(A')mu),
 //   d2/du_i du_j [mu' exp(A) x] = sum_{a,b} B(a,b) ( pt_b' E_i d^j_a + pt_b' E_j d^i_a ),  B(a,b) = a! b! / (a+b+1)!
 // (split the word mu' ... E ... E ... x at its LEFT generator: what stands to its right is a first-order forward
 // term, what stands to its left a plain adjoint term, and the Taylor terms of exp(tau A) and exp((1-tau)A')
 // integrate against each other over tau in [0,1]).  With U_a = sum_b B(a,b) pt_b (k_pair_combine, type 0 only) and
 // EP[j][a] = G_j' U_a (one generator product per drive and term), the block is  sum_a EP[i][a].d^j_a + EP[j][a].d^i_a.
+// The scalar mu' exp(A) x = x' exp(A') mu is symmetric under (A, x, mu, G) <-> (A', mu, x, G'), and the engine uses the
+// transposed reading: the tangents come from the ADJOINT sweep (which the (x,u) block needs anyway), the plain terms from a
+// forward sweep of the p column alone, EP[j][a] = G_j U_a.  `fw` below is the sweep that carries the tangents.
 __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw, int nf_used,
                                                    const double* __restrict__ EP, double* __restrict__ H) {
     __shared__ double red[4][MAX_DRIVES * MAX_DRIVES];
@@ -1868,13 +1872,37 @@ __global__ void __launch_bounds__(256) k_hess_bilinear(KProb P, KBil B, SweepBuf
         hess_add(P, H, kn, B.x_off + r, P.dt_idx, -ad.GY[col + r]);
     }
     // scalar blocks: block-wide dot products
+    if (!with_uu) {
+        // pairing path: only the ADJOINT sweep carries tangents.  With V_l = G_l x (fw.W), gx = G(u) x, pt = exp(A')mu and
+        // dt^j = L(A, dt G_j)' mu (ad.S), the identity  G L(A,E) = L(A,E) G + (exp(A) E - E exp(A))/dt  (E = dt G_j) turns
+        //   d2/du_j ddt = mu' G_j exp(A) x + mu' G L(A,E) x   into   dt^j . gx + pt . V_j,
+        // and  d2/ddt2 = mu' G G exp(A) x = (G' pt) . gx  since G commutes with exp(A): no forward tangent, no forward sum.
+        auto gx = [&](int r) {
+            double s = 0.0;
+            for (int l = 0; l <= m; ++l) s += ad.scaleU[(int64_t)l * ad.Kpad + kl] * fw.W[l * ts + col + r];
+            return s;
+        };
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int r = threadIdx.x; r < n; r += blockDim.x)
+                s += ad.S[(1 + j) * ts + col + r] * gx(r) + ad.S[col + r] * fw.W[(1 + j) * ts + col + r];
+            s = block_sum_256(s, sm);
+            __syncthreads();
+            if (threadIdx.x == 0) hess_add(P, H, kn, B.u_off + j, P.dt_idx, -s);
+        }
+        double s = 0.0;
+        for (int r = threadIdx.x; r < n; r += blockDim.x) s += ad.GY[col + r] * gx(r);
+        s = block_sum_256(s, sm);
+        if (threadIdx.x == 0) atomicAdd(&H[hess_pos(P, kn, P.dt_idx, P.dt_idx)], -s);
+        return;
+    }
     auto gm = [&](int r) {
         double s = 0.0;
         for (int l = 0; l <= m; ++l) s += fw.scaleU[(int64_t)l * fw.Kpad + kl] * ad.W[l * ts + col + r];
         return s;
     };
     int hidx = 1 + m;
-    for (int i = 0; i < (with_uu ? m : 0); ++i)
+    for (int i = 0; i < m; ++i)
         for (int j = i; j < m; ++j, ++hidx) {
             double s = 0.0;
             for (int r = threadIdx.x; r < n; r += blockDim.x) s += muk[r] * fw.S[hidx * ts + col + r];

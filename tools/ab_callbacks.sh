@@ -1,0 +1,8 @@
+#!/bin/bash
+run() { DTO_ENGINE_LIB=$1 timeout -k 10 120 python bench.py --no-cpu-baseline --no-other-callbacks --callback $2 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1 $2', round(d['ms_per_step'],3))"; }
+for rep in 1 2 3; do
+  for cb in constraint hessian; do
+    run libdto_engine.so $cb
+    run libdto_engine_r01g.so $cb
+  done
+done
