@@ -30,3 +30,9 @@ for cb in ("constraint","jacobian","hessian"):
     run(32, 4, 100, cb, steps=5)
 for cb in ("constraint","jacobian","hessian"):
     run(17, 3, 1000, cb, steps=5)
+if "--big" in sys.argv:
+    for cb in ("jacobian", "hessian"):
+        run(256, 4, 16000, cb, steps=2)  # configs[3] unsharded
+for n in (128, 512):
+    for cb in ("jacobian", "hessian"):
+        run(n, 4, 1000 if n == 128 else 500, cb)
