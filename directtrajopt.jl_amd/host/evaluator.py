@@ -353,7 +353,8 @@ class Evaluator:
         self._check(self._lib.dto_eval_hessian_dev(self._h, dZ, float(sigma), dmu, dvals, stream))
 
     def set_option(self, name, value):
-        """dto_set_option: e.g. ``reuse_forward_sweep`` (solver loops evaluate g, J, H at the same point)."""
+        """dto_set_option: ``reuse_forward_sweep`` (solver loops evaluate g, J, H at the same point), ``expm_form``
+        (0 = by cost, 2 / 3 = two- / three-product form of the Jacobian's matrix exponential)."""
         self._check(self._lib.dto_set_option(self._h, name.encode(), int(value)))
 
     # ---- measurement
