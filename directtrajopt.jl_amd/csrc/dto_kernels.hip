@@ -118,19 +118,20 @@ void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const Basi
 }
 
 // out[:, b] = S * coef[:, b]  for the nb intervals of the chunk (FP64 MFMA, same GEMM core).
-__global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSet bs, double* __restrict__ out,
-                                                       double* __restrict__ colsum) {
-    using Cfg = GemmCfg<128, 128>;
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::THREADS, 2) k_basis_gemm(int npad, int nb, BasisSet bs, double* __restrict__ out,
+                                                                double* __restrict__ colsum) {
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
     const int64_t nn = (int64_t)npad * npad;
-    const int row_tiles = (int)(nn / 128);
+    const int row_tiles = (int)(nn / TM);
     const int rt = blockIdx.x % row_tiles, ct = blockIdx.x / row_tiles;
-    GemmAcc<128, 128> acc;
+    GemmAccS<Cfg> acc;
     acc.zero();
-    gemm_accumulate<128, 128>(acc, bs.S + (int64_t)rt * 128, (int)nn, bs.coef + (int64_t)ct * 128 * bs.cntpad, bs.cntpad,
-                              bs.cntpad, nullptr, smem);
-    GemmCoord<128, 128> co;
-    const int row0 = rt * 128 + co.row_base, col0 = ct * 128 + co.col_base;
+    gemm_accumulate_s<Cfg>(acc, bs.S + (int64_t)rt * TM, (int)nn, bs.coef + (int64_t)ct * TN * bs.cntpad, bs.cntpad,
+                           bs.cntpad, nullptr, smem);
+    GemmCoordS<Cfg> co;
+    const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
 #pragma unroll
     for (int tj = 0; tj < Cfg::NT; ++tj)
 #pragma unroll
@@ -145,10 +146,11 @@ __global__ void __launch_bounds__(256, 2) k_basis_gemm(int npad, int nb, BasisSe
             if (colsum) {
                 // the wave's 64 rows lie inside ONE column of the npad x npad matrix (npad multiple of 128):
                 // reduce over the 16 lanes sharing this interval, then one atomic per (interval, matrix column)
+                static_assert(Cfg::WTM == 64, "column sums assume 64-row wave tiles");
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
                 if ((threadIdx.x & 15) == 0 && col < nb)
-                    atomicAdd(&colsum[(int64_t)col * npad + (rt * 128 + (co.row_base & ~63)) / npad], asum);
+                    atomicAdd(&colsum[(int64_t)col * npad + (rt * TM + (co.row_base & ~63)) / npad], asum);
             }
         }
 }
@@ -174,7 +176,10 @@ void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* col
 }
 void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum) {
     const int64_t nn = (int64_t)npad * npad;
-    hipLaunchKernelGGL(k_basis_gemm, dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(256), 0, st, npad, nb, bs, out, colsum);
+    // 8 waves of 64x32 per 128x128 tile: the K loop is only 1..8 panels long, more waves hide its prologue and the
+    // store-heavy epilogue better than 4 waves of 64x64 (measured -7 % per launch at 256x2000; 128x64 tiles +9 %)
+    using C = GemmShape<128, 128, 2, 4, 16>;
+    hipLaunchKernelGGL((k_basis_gemm<C>), dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(C::THREADS), 0, st, npad, nb, bs, out, colsum);
 }
 
 // One wavefront per column c of the owned knots: walk the column's entries in the structure's order
