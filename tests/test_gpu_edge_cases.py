@@ -174,6 +174,35 @@ def test_generic_path_on_small_states_in_subprocess():
     assert r.returncode == 0 and "generic-ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_chunked_propagator_chain_in_subprocess():
+    """DTO_CHAIN_CHUNK=8 splits the 20 intervals of the chain into three chunks (what 16000 knots do with the default
+    workspace budget): each chunk reads back its own squaring counts and picks its own polynomial form -- the time steps
+    are chosen so that the chunks disagree (alpha ~ 1.5 in the first, ~ 4.5 in the others)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os\n"
+        "root = os.environ['DTO_ROOT']\n"
+        "for p in (root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')): sys.path.insert(0, p)\n"
+        "import numpy as np, dto_amd, dto_oracle as O\n"
+        "from helpers import to_engine, rel_err\n"
+        "p = O.make_scaled_problem(21, 40, 3, seed=9)\n"
+        "Z = p.Z0.copy(); dt = np.full(p.N, 0.75); dt[:8] = 0.25; Z[p.dt_idx::p.z] = dt\n"
+        "ref = O.OracleEvaluator(p).eval_constraint_jacobian(Z)\n"
+        "ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)\n"
+        "for form in (0, 2, 3):\n"
+        "    ev.set_option('expm_form', form)\n"
+        "    j = np.full(ev.shard.jac_len, np.nan); ev.eval_constraint_jacobian(j, Z)\n"
+        "    assert rel_err(j, ref) <= 1e-10, (form, rel_err(j, ref))\n"
+        "ev.close()\n"
+        "print('chunked-ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTO_CHAIN_CHUNK="8", DTO_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "chunked-ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_large_norm_on_the_general_path_uses_substeps_and_many_squarings():
     """n > 16 with big time steps: the sweeps need q > 1 rounds (which also takes the Hessian off the
     pairing path, onto second-order columns) and the chain several squarings."""
