@@ -188,7 +188,7 @@ def test_chunked_propagator_chain_in_subprocess():
         "import numpy as np, dto_amd, dto_oracle as O\n"
         "from helpers import to_engine, rel_err\n"
         "p = O.make_scaled_problem(21, 40, 3, seed=9)\n"
-        "Z = p.Z0.copy(); dt = np.full(p.N, 0.75); dt[:8] = 0.25; Z[p.dt_idx::p.z] = dt\n"
+        "Z = p.Z0.copy(); dt = np.full(p.N, 0.28); dt[:8] = 0.09; Z[p.dt_idx::p.z] = dt\n"
         "ref = O.OracleEvaluator(p).eval_constraint_jacobian(Z)\n"
         "ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)\n"
         "for form in (0, 2, 3):\n"
