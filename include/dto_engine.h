@@ -243,7 +243,8 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value);
 int dto_profile_enable(dto_handle* h, int32_t on);
 int dto_profile_reset(dto_handle* h);
 /* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain: every template instance), its parts
- * "bgemm_horner" / "bgemm_square" / "bgemm_plain", "basis" (generator-subspace GEMM), "expmv" (sweep step), "all".
+ * "bgemm_horner" (the products with a fused polynomial epilogue) / "bgemm_square" / "bgemm_plain", "basis"
+ * (generator-subspace GEMM), "expmv" (sweep step), "all".
  * Returns accumulated device milliseconds, launches and algorithmic FLOPs of those launches. */
 int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops);
 /* diagnostics of the last Jacobian call: max squarings used, Taylor terms used by the tangent sweep */
