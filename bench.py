@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--callback", default="jacobian", choices=["jacobian", "hessian", "constraint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-callbacks", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="leave the engine's HIP-event kernel timing off (measures its cost; the roofline block is then empty)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -152,7 +154,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    ev.profile_enable(True)  # warm-up runs with the timing events on too; they are recycled by profile_reset
+    ev.profile_enable(not args.no_kernel_timing)  # warm-up runs with the timing events on too; they are recycled by profile_reset
     for _ in range(args.warmup):
         step()
     fence()
@@ -230,9 +232,14 @@ def main():
                                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": nbytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS})(
                 8.0 * (out.numel() + Z.numel() + (m + 1) * n * n + (ev.n_constraints if args.callback == "hessian" else 0))),
-            "secondary_kernel": {"kernel": "k_sweep (generator sweep: exp(A)x and its u-tangents)",
-                                 "ms_per_step": ms_sweep / args.steps, "launches": n_sweep,
-                                 "achieved_tflops": fl_sweep / (ms_sweep * 1e-3) / 1e12 if ms_sweep > 0 else 0.0},
+            # one timed region per sweep (its step kernels, termination tests and the gaps between them); flops = the
+            # generator products of the Taylor terms actually used: 2 npad^2 (m+1) products per column, (1+m) column types
+            # (Jacobian; the Hessian's two sweeps and the constraint's single column are priced by the engine's own count)
+            "secondary_kernel": (lambda fl: {"kernel": "k_sweep (generator sweep: exp(A)x and its u-tangents)",
+                                             "ms_per_step": ms_sweep / args.steps, "timed_regions": n_sweep,
+                                             "achieved_tflops": fl / (ms_sweep * 1e-3) / 1e12 if ms_sweep > 0 else 0.0})(
+                (2.0 * (-(-n // 64) * 64) ** 2 * (-(-(Nk - 1) // 128) * 128) * (m + 1) * (m + 1) * terms * args.steps)
+                if args.callback == "jacobian" else fl_sweep),
         }
         if world == 1 and args.callback == "jacobian" and not args.no_other_callbacks:
             # the other callbacks of the same problem, same protocol (3 untimed + 5 timed calls each): reported for
