@@ -471,7 +471,16 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
         launched = 0;
         bool pending = false;
         int slot = 0;
+        // The termination test cannot fire early in the series: it is first run at step tc = d_ub/2 - 1 (d_ub comes from
+        // an upper bound on the terms needed at this very Z, so tc is a function of Z alone and results stay reproducible;
+        // a column block that would pass earlier merely adds a few terms below 1e-16 of its sum).  Each test left out is one
+        // kernel and one dependent-launch gap less (~12 us).  The term-norm slots the tests recycle are cleared once instead.
+        static const int tc_env = [] { const char* e = getenv("DTO_SWEEP_TC"); return e ? atoi(e) : -1; }();
+        int tc = tc_env >= 0 ? tc_env : plan.d_ub / 2 - 1;
+        if (tc < 2) tc = 0;
         for (int t = 0; t < plan.d_ub; ++t) {
+            if (tc > 0 && t == tc - 1)
+                HIP_CHECK(hipMemsetAsync(w.termnorm, 0, sizeof(unsigned long long) * (size_t)3 * w.T_alloc * w.Kpad, st));
             {
                 ps.r.flops += flops_step;
                 if (store) {
@@ -484,7 +493,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
                     launch_sweep_step(st, b.k, w, ty, transposed, t, buf);
                 }
             }
-            launch_sweep_check(st, w, ty.T, t, 1.1e-16);
+            if (t >= tc) launch_sweep_check(st, w, ty.T, t, 1.1e-16);
             buf ^= 1;
             launched = t + 1;
             // Every 4 steps the number of still-active column blocks (4 bytes) is copied back; the copy of the
