@@ -235,12 +235,28 @@ __global__ void __launch_bounds__(256) k_jac_zero(KProb P, KBil B, double* __res
     const int cnt = has_prev + has_own;
     const bool skipE = has_own && (int64_t)blockIdx.x < P.n_int;
     const int64_t e_lo = (int64_t)B.pre * cnt + (has_prev ? B.n : 0);  // offset of the E rows inside an x column
-    for (int j = blockIdx.y; j < P.z; j += gridDim.y) {
+    // 16-byte stores over the 16-byte-aligned interior of [lo, hi), scalar stores at an odd head / tail; a column holds
+    // a few hundred entries, so each half of the workgroup takes its own column
+    const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
+    auto zero_range = [&](int64_t lo, int64_t hi) {
+        if (hi <= lo) return;
+        const int64_t a = lo + (int64_t)((reinterpret_cast<uintptr_t>(vals + lo) >> 3) & 1);
+        if (lane == 0 && a > lo) vals[lo] = 0.0;
+        const int64_t npair = hi > a ? (hi - a) / 2 : 0;
+        d2* q = reinterpret_cast<d2*>(vals + a);
+        for (int64_t i = lane; i < npair; i += 128) q[i] = d2{0.0, 0.0};
+        if (lane == 0 && a + 2 * npair < hi) vals[hi - 1] = 0.0;
+    };
+    for (int j = 2 * blockIdx.y + half; j < P.z; j += 2 * gridDim.y) {
         const int64_t c = kn * P.z + j;
         const int64_t e0 = P.colptr[c] - P.jac_lo, len = P.colptr[c + 1] - P.colptr[c];
         const bool xcol = skipE && j >= B.x_off && j < B.x_off + B.n;
-        for (int64_t e = threadIdx.x; e < len; e += 256)
-            if (!(xcol && e >= e_lo && e < e_lo + B.n)) vals[e0 + e] = 0.0;
+        if (xcol) {
+            zero_range(e0, e0 + e_lo);
+            zero_range(e0 + e_lo + B.n, e0 + len);
+        } else {
+            zero_range(e0, e0 + len);
+        }
     }
 }
 void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals) {
@@ -305,6 +321,7 @@ __global__ void __launch_bounds__(256) k_build_A(KProb P, KBil B, const double* 
     for (int j = 0; j < B.m; ++j) ub[j + 1] = dt * zk[B.u_off + j];
     const int64_t nn = (int64_t)B.npad * B.npad;
     double* Ab = A + (int64_t)b * nn;
+#pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nn / 2; i += (int64_t)gridDim.x * 256) {
         d2 acc = {0.0, 0.0};
         for (int j = 0; j <= B.m; ++j) {
@@ -312,13 +329,14 @@ __global__ void __launch_bounds__(256) k_build_A(KProb P, KBil B, const double* 
             acc.x += ub[j] * g.x;
             acc.y += ub[j] * g.y;
         }
-        reinterpret_cast<d2*>(Ab)[i] = acc;
+        __builtin_nontemporal_store(acc, &reinterpret_cast<d2*>(Ab)[i]);
     }
 }
 void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, int64_t int0, int nb, double* A) {
     const int64_t nn2 = (int64_t)B.npad * B.npad / 2;
     int gx = (int)((nn2 + 255) / 256);
-    if (gx > 64) gx = 64;
+    static const int cap = [] { const char* e = getenv("DTO_BUILDA_GX"); return e ? atoi(e) : 16; }();
+    if (gx > cap) gx = cap;
     hipLaunchKernelGGL(k_build_A, dim3(gx, nb), dim3(256), 0, st, P, B, dZ, int0, A);
 }
 
