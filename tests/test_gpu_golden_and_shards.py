@@ -104,6 +104,28 @@ def test_device_pointer_entry_points_match_host_entry_points():
     ev.close()
 
 
+def test_jacobian_into_an_8_byte_aligned_device_buffer():
+    """The C ABI promises nothing about the alignment of the caller's value buffer beyond that of a double: the general
+    path (40 states; its zero-fill uses 16-byte stores where it can) must write the same numbers at an odd offset."""
+    import torch
+    import dto_amd
+    p = O.make_scaled_problem(5, 40, 2, seed=4, with_constraint=True)
+    ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)
+    dev = torch.device("cuda", 0)
+    dZ = torch.from_numpy(p.Z0).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = ev.n_jacobian_entries
+    a = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    b = torch.full((n + 3,), float("nan"), dtype=torch.float64, device=dev)
+    ev.eval_jacobian_dev(dZ.data_ptr(), a.data_ptr(), st)
+    ev.eval_jacobian_dev(dZ.data_ptr(), b.data_ptr() + 8, st)
+    torch.cuda.synchronize()
+    assert a.data_ptr() % 16 == 0
+    assert torch.equal(a, b[1:n + 1]) and bool(torch.isfinite(a).all())
+    assert bool(torch.isnan(b[0])) and bool(torch.isnan(b[n + 1:]).all())  # nothing written outside the slab
+    ev.close()
+
+
 def test_full_size_properties_256x2000():
     """BASELINE configs[2] size: parity through size-independent properties (the oracle would need
     hours here): (1) the x_k Jacobian block of interval k is -exp(dt G(u_k)), checked against the
