@@ -1172,45 +1172,51 @@ void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int n_types,
 // The scalar mu' exp(A) x = x' exp(A') mu is symmetric under (A, x, mu, G) <-> (A', mu, x, G'), and the engine uses the
 // transposed reading: the tangents come from the ADJOINT sweep (which the (x,u) block needs anyway), the plain terms from a
 // forward sweep of the p column alone, EP[j][a] = G_j U_a.  `fw` below is the sweep that carries the tangents.
+template <int M>
 __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw, int nf_used,
                                                    const double* __restrict__ EP, double* __restrict__ H) {
-    __shared__ double red[4][MAX_DRIVES * MAX_DRIVES];
+    __shared__ double red[4][M * M];
     const int64_t kl = blockIdx.x;
     const int64_t kn = P.kn_lo + kl;
-    const int n = B.n, m = B.m, npad = fw.npad, T = 1 + m;
+    constexpr int m = M;  // drives: compile-time so that the accumulators live in registers
+    const int n = B.n, npad = fw.npad, T = 1 + m;
     const int64_t typesz = (int64_t)fw.Kpad * npad;
     const int64_t tstride = (int64_t)T * typesz;          // one stored Taylor term of all forward types
     const int64_t gstride = (int64_t)nf_used * typesz;    // one generator in EP (nf_used terms)
     int nf = fw.nterms[kl / fw.TN];
     if (nf <= 0 || nf > nf_used) nf = nf_used;
-    double acc[MAX_DRIVES][MAX_DRIVES];
+    double acc[M][M];
     for (int i = 0; i < m; ++i)
         for (int j = 0; j < m; ++j) acc[i][j] = 0.0;
-    for (int r = threadIdx.x; r < n; r += 256) {
+    // 16-byte loads: a thread owns two adjacent rows (the padding rows hold zeros), the two halves of the workgroup take the
+    // even and the odd terms
+    const int half = threadIdx.x >> 7;
+    for (int r = 2 * (threadIdx.x & 127); r < npad; r += 256) {
         const int64_t off = kl * npad + r;
-        for (int a = 0; a < nf; ++a) {
+        for (int a = half; a < nf; a += 2) {
             const double* Da = fw.Zt + a * tstride + off;
             const double* Ea = EP + a * typesz + off;
-            double Et[MAX_DRIVES], D[MAX_DRIVES];
+            d2 Et[M], D[M];
             for (int j = 0; j < m; ++j) {
-                Et[j] = Ea[j * gstride];
-                D[j] = Da[(1 + j) * typesz];
+                Et[j] = *reinterpret_cast<const d2*>(Ea + j * gstride);
+                D[j] = *reinterpret_cast<const d2*>(Da + (1 + j) * typesz);
             }
             for (int i = 0; i < m; ++i)
-                for (int j = i; j < m; ++j) acc[i][j] += Et[i] * D[j] + Et[j] * D[i];
+                for (int j = i; j < m; ++j)
+                    acc[i][j] += Et[i].x * D[j].x + Et[j].x * D[i].x + Et[i].y * D[j].y + Et[j].y * D[i].y;
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = 0; i < m; ++i)
         for (int j = i; j < m; ++j) {
             const double v = wave_sum(acc[i][j]);
-            if (lane == 0) red[wave][i * MAX_DRIVES + j] = v;
+            if (lane == 0) red[wave][i * M + j] = v;
         }
     __syncthreads();
     if (threadIdx.x < m * m) {
         const int i = threadIdx.x / m, j = threadIdx.x % m;
         if (i <= j) {
-            const int q = i * MAX_DRIVES + j;
+            const int q = i * M + j;
             const double dt = fw.scaleE[kl];  // dt/q with q = 1 on this path
             hess_add(P, H, kn, B.u_off + i, B.u_off + j, -dt * (red[0][q] + red[1][q] + red[2][q] + red[3][q]));
         }
@@ -1219,7 +1225,16 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
 void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* EP,
                       double* H) {
     if (P.n_int <= 0) return;
-    hipLaunchKernelGGL(k_hess_pair, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, nf_used, EP, H);
+    const dim3 grid((unsigned)P.n_int), block(256);
+    switch (B.m) {
+        case 1: hipLaunchKernelGGL(k_hess_pair<1>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+        case 2: hipLaunchKernelGGL(k_hess_pair<2>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+        case 3: hipLaunchKernelGGL(k_hess_pair<3>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+        case 4: hipLaunchKernelGGL(k_hess_pair<4>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+        case 5: hipLaunchKernelGGL(k_hess_pair<5>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+        case 6: hipLaunchKernelGGL(k_hess_pair<6>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+        default: hipLaunchKernelGGL(k_hess_pair<MAX_DRIVES>, grid, block, 0, st, P, B, fw, nf_used, EP, H); break;
+    }
 }
 
 void launch_apply_Gu(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V, double* out) {
