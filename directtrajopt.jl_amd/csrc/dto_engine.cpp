@@ -641,8 +641,11 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     s_ub = std::min(s_ub, 60);
     const double gemm_flops = 2.0 * npad * (double)npad * npad;
     h->last_smax = 0;
-    for (int64_t c0 = 0; c0 < nint; c0 += cap) {
-        const int nb = (int)std::min<int64_t>(cap, nint - c0);
+    // chunks of equal size (a multiple of 8 intervals) rather than full ones plus a remainder
+    const int64_t nchunk = (nint + cap - 1) / cap;
+    const int per = (int)std::min<int64_t>(cap, (((nint + nchunk - 1) / nchunk) + 7) / 8 * 8);
+    for (int64_t c0 = 0; c0 < nint; c0 += per) {
+        const int nb = (int)std::min<int64_t>(per, nint - c0);
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
         launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
