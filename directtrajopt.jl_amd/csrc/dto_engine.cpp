@@ -700,14 +700,15 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         }
         // Y = A^4 K -> (Y + Pa, Y + Pb) in one launch
         { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 3, 5, 4, COEF_PA, 6, COEF_PB); }
+        const SlabDest slab{h->P, b.k, int0, vals};  // intervals with s_k = 0: the last product is exp(A_k) itself
         if (form == 2) {
             // T_16 = (Y + Pa)(Y + Pb) + Pc
             ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb);
-            launch_bgemm_poly(st, npad, nb, w, 4, 6, 5, COEF_PC, -1, 0);
+            launch_bgemm_poly(st, npad, nb, w, 4, 6, 5, COEF_PC, -1, 0, false, &slab);
         } else {
             // (L, R) = Ya Yb + weights of Ya + polynomials, then r = L R + Pe
             { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 4, 6, 7, COEF_L, 8, COEF_R, true); }
-            { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 7, 8, 5, COEF_PC, -1, 0); }
+            { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 7, 8, 5, COEF_PC, -1, 0, false, &slab); }
         }
         const int s_max = form == 3 ? hs[4] : hs[0];
         const int s_sum = form == 3 ? hs[5] : hs[1];

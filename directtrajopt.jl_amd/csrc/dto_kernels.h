@@ -147,10 +147,18 @@ void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w);
 // coefficient table (and w.s) for the chosen form: 2 = two products (degree 16), 3 = three products (order 26)
 void launch_expm_coef(hipStream_t st, int nb, const ChainWork& w, int form);
 void launch_poly_h3(hipStream_t st, int npad, int nb, const ChainWork& w);
+// where exp(A_k) of the intervals that need no squaring goes: the x_k columns of the Jacobian slab
+struct SlabDest {
+    KProb P;
+    KBil B;
+    int64_t int0;
+    double* vals;
+};
 // W[dst] = W[srcA] W[srcB] + poly(coef_base);  dst2 >= 0: also W[dst2] = W[srcA] W[srcB] + poly(coef_base2);
-// with_srcA: each polynomial has a sixth coefficient, the weight of W[srcA] itself
+// with_srcA: each polynomial has a sixth coefficient, the weight of W[srcA] itself;
+// slab (single-output form, the LAST polynomial product): intervals with s_k = 0 store -result into the Jacobian slab
 void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int srcA, int srcB, int dst, int coef_base,
-                       int dst2, int coef_base2, bool with_srcA = false);
+                       int dst2, int coef_base2, bool with_srcA = false, const SlabDest* slab = nullptr);
 void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
                          const KProb& P, const KBil& B, int64_t int0, double* vals);
 

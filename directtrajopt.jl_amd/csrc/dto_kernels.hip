@@ -423,6 +423,8 @@ k_bgemm(BGemmArgs a) {
         }
 
         double* Cb = a.C + b * nn;
+        // the final polynomial product of an interval that needs no squaring IS exp(A_k): it goes into the Jacobian slab
+        const bool to_slab = EPI == EPI_HORNER && a.vals != nullptr && a.s[b] == 0;
         double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
         const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr, *M5 = nullptr;
         double* Cb2 = nullptr;
@@ -442,6 +444,9 @@ k_bgemm(BGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = col0 + 16 * tj + 4 * r;
+                int64_t slab_base = 0;
+                if (EPI == EPI_HORNER && to_slab && col < a.Bi.n)
+                    slab_base = jac_pos(a.P, a.P.colptr, a.int0 + b, a.Bi.x_off + col, a.Bi.pre, a.Bi.n, 1, 0);
 #pragma unroll
                 for (int ti = 0; ti < Cfg::MT; ++ti) {
                     const int row = row0 + 16 * ti;
@@ -465,6 +470,10 @@ k_bgemm(BGemmArgs a) {
                         }
                         v2 += c1 * m1 + c2 * m2 + c3 * m3 + c4 * m4;  // streamed once per stage
                         if (row == col) v2 += c0;
+                    }
+                    if (EPI == EPI_HORNER && to_slab) {
+                        if (col < a.Bi.n && row < a.Bi.n) __builtin_nontemporal_store(-v2, &a.vals[slab_base + row]);
+                        continue;
                     }
                     __builtin_nontemporal_store(v2, &Cb[off]);  // 1 GB per launch: gone from L2 before its reader starts
                 }
@@ -552,8 +561,9 @@ void launch_bgemm_plain(hipStream_t st, int npad, int nb, const double* A, const
     launch_bgemm<EPI_PLAIN>(st, a);
 }
 void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int srcA, int srcB, int dst, int coef_base,
-                       int dst2, int coef_base2, bool with_srcA) {
+                       int dst2, int coef_base2, bool with_srcA, const SlabDest* slab) {
     BGemmArgs a{};
+    if (slab) { a.s = w.s; a.P = slab->P; a.Bi = slab->B; a.int0 = slab->int0; a.vals = slab->vals; }
     a.A = w.W[srcA]; a.B = w.W[srcB]; a.C = w.W[dst]; a.npad = npad; a.nbatch = nb;
     a.M1 = w.W[0]; a.M2 = w.W[1]; a.M3 = w.W[2]; a.M4 = w.W[3]; a.coef = w.coef; a.coef_base = coef_base;
     if (dst2 >= 0) {
@@ -680,8 +690,8 @@ void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int 
 
 // Scaling parameter s_k for both evaluation forms of the polynomial (sigma = 2^-s_k).
 // alpha_p(A) = max(||A^p||^(1/p), ||A^(p+1)||^(1/(p+1))) bounds the truncation series for
-// p(p-1) <= m+1 (Al-Mohy & Higham 2009, Thm 4.2); s_k = ceil(log2(alpha / theta)), at least 1 so
-// that the last product of the chain is always a squaring (the one that stores into the Jacobian).
+// p(p-1) <= m+1 (Al-Mohy & Higham 2009, Thm 4.2); s_k = max(0, ceil(log2(alpha / theta))).  Whatever runs last for an
+// interval -- its s_k-th squaring, or the final polynomial product when s_k = 0 -- stores -exp(A_k) into the Jacobian.
 __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
@@ -690,7 +700,7 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     const double d3v = cbrt(w.norms[b * 4 + 2]);
     const double d4v = sqrt(sqrt(w.norms[b * 4 + 3]));
     double alpha = fmin(n1, fmin(fmax(d2v, d3v), fmax(d3v, d4v)));
-    int s = 1;
+    int s = 0;  // no squaring at all inside the radius: the last polynomial product then stores into the Jacobian itself
     if (alpha > THETA_16) {
         s = (int)ceil(log2(alpha / THETA_16));
         if (s < 1) s = 1;
@@ -700,7 +710,7 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
     w.s[b] = s;
     atomicMax(&w.smax[0], s);
     atomicAdd(&w.smax[1], s);
-    int s3 = 1;
+    int s3 = 0;
     if (alpha > THETA_3P) {
         s3 = (int)ceil(log2(alpha / THETA_3P));
         if (s3 < 1) s3 = 1;

@@ -165,7 +165,7 @@ def test_generic_path_on_small_states_in_subprocess():
         "    assert rel_err(out['cons'], ev_o.eval_constraint(p.Z0)) <= 1e-10\n"
         "    assert rel_err(out['jac'], ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10\n"
         "    assert rel_err(out['hess'], ev_o.eval_hessian_lagrangian(p.Z0, 0.5, mu)) <= 1e-8\n"
-        "    assert ev.last_stats()[0] >= 1  # the propagator chain ran\n"
+        "    assert ev.last_stats()[1] >= 1  # the generator sweep of the general path ran (the fused kernel reports 0 terms)\n"
         "    ev.close()\n"
         "print('generic-ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -200,6 +200,35 @@ def test_both_polynomial_forms_of_the_matrix_exponential(n, m):
         ev.close()
 
 
+@pytest.mark.parametrize("n,m,scale", [(64, 3, 0.15), (128, 2, 0.5), (40, 4, 0.6)])
+def test_no_squaring_inside_the_radius(n, m, scale):
+    """Small steps (alpha below the radius of the polynomial form in use): the last polynomial product is exp(A_k) itself and
+    stores into the Jacobian slab -- no squaring launch.  scale = 0.15 stays inside the degree-16 radius (two products),
+    0.5 and 0.6 are inside the order-26 radius only; a trajectory that mixes both kinds of interval is checked as well."""
+    import dto_amd
+    p = O.make_scaled_problem(5, n, m, seed=n + m)
+    Z = p.Z0.copy()
+    Z[p.dt_idx::p.z] = 0.1 * np.sqrt(256.0 / n) * scale
+    ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)
+    try:
+        for form in (2, 3, 0):
+            ev.set_option("expm_form", form)
+            j = np.full(ev.shard.jac_len, np.nan)
+            ev.eval_constraint_jacobian(j, Z)
+            sq = ev.last_stats()[0]
+            assert rel_err(j, O.OracleEvaluator(p).eval_constraint_jacobian(Z)) <= TOL, (form, sq)
+            if form == 3 or (form == 2 and scale <= 0.15):
+                assert sq == 0, (form, sq)
+        Zm = Z.copy()
+        Zm[p.dt_idx::p.z] = 0.1 * np.sqrt(256.0 / n) * np.array([0.1, 1.5, 0.1, 3.0, 0.1])
+        ev.set_option("expm_form", 0)
+        j = np.full(ev.shard.jac_len, np.nan)
+        ev.eval_constraint_jacobian(j, Zm)
+        assert rel_err(j, O.OracleEvaluator(p).eval_constraint_jacobian(Zm)) <= TOL
+    finally:
+        ev.close()
+
+
 def test_external_integrator_merged_from_host_blocks():
     """an integrator evaluated outside the engine (the shape TimeDependentBilinearIntegrator has:
     both knot halves of the Jacobian block, cross part of the Hessian block) placed between built-in integrators."""
