@@ -73,6 +73,10 @@ struct BilHost {
     // reuse_forward_sweep: what b.fw still holds for the cached Z -- 0 nothing, 1 the p sums (S type 0), 2 p and d^j sums
     // and GY, 3 additionally every Taylor term in fw.Zt (cache_steps of them)
     int cache_kind = 0, cache_steps = 0;
+    // ... and whether the Taylor terms of the p column of that point sit in fw.Zt ([term][Kpad][npad], one type per term:
+    // eval_constraint and the Hessian's forward sweep store them), p_steps + 1 of them, valid counts per block in fw.nterms_p
+    bool p_terms = false;
+    int p_steps = 0;
     bool small = false;       // n <= 32: fused one-workgroup-per-interval path (dto_small.hip)
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
@@ -453,13 +457,14 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
               bool skip_init = false) {
     const double flops_step = [&] {
         double segs = 0;
-        for (int t = 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
+        for (int t = w.frozen ? w.first_type : 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
         return 2.0 * b.k.npad * (double)b.k.npad * w.Kpad * segs;
     }();
     const size_t tstride = (size_t)ty.T * w.Kpad * w.npad;
     SweepBuf ws = w;
     if (store) ws.Z[0] = w.Zt;
-    if (!skip_init) launch_sweep_init(st, h->P, b.k, ws, ty, dZ, dmu, src_kind, plan.q);
+    if (w.frozen) launch_sweep_init_tangents(st, ws, ty.T);  // scale factors and type-0 sums are those of the earlier callback
+    else if (!skip_init) launch_sweep_init(st, h->P, b.k, ws, ty, dZ, dmu, src_kind, plan.q);
     int launched = 0;
     // one timed region per sweep (steps, termination tests and the gaps between them): an event pair per step costs
     // 0.2 ms per Jacobian call at 256x2000.  Its flop count covers every enqueued step, including the few that find their
@@ -821,7 +826,7 @@ bool same_point(dto_handle* h, const double* dZ, hipStream_t st) {
         h->d_Zcache = own(h, dalloc<double>((size_t)h->n_vars));
         h->d_eq = own(h, dalloc<int32_t>(1));
         HIP_CHECK(hipMemcpyAsync(h->d_Zcache, dZ, sizeof(double) * (size_t)h->n_vars, hipMemcpyDeviceToDevice, st));
-        for (auto& b : h->bil) b.cache_kind = 0;
+        for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
         return false;
     }
     int32_t* flag = reinterpret_cast<int32_t*>(h->h_pinned + 24);
@@ -832,7 +837,7 @@ bool same_point(dto_handle* h, const double* dZ, hipStream_t st) {
     HIP_CHECK(hipStreamSynchronize(st));
     if (*flag) return true;
     HIP_CHECK(hipMemcpyAsync(h->d_Zcache, dZ, sizeof(double) * (size_t)h->n_vars, hipMemcpyDeviceToDevice, st));
-    for (auto& b : h->bil) b.cache_kind = 0;
+    for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
     return false;
 }
 
@@ -863,6 +868,14 @@ void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st)
         if (e.k.n_list > 0) launch_ext_gradient(st, h->P, e.k, e.weight, ext_upload(h, e.ext_slot, 1, st), dgrad);
 }
 
+// after a stored sweep of the p column alone: its terms stay valid for later callbacks at the same point
+void remember_p_terms(dto_handle* h, BilHost& b, bool stored, int steps, hipStream_t st) {
+    b.p_terms = stored && h->reuse;
+    b.p_steps = steps;
+    if (stored)
+        HIP_CHECK(hipMemcpyAsync(b.fw.nterms_p, b.fw.nterms, sizeof(int32_t) * (b.fw.Kpad / b.fw.TN), hipMemcpyDeviceToDevice, st));
+}
+
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
     const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
@@ -874,8 +887,12 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
             if (!(same && b.cache_kind >= 1)) {  // else exp(A)x of this very point is still in b.fw.S
                 SweepPlan plan = plan_from(h, b, dZ, st);
                 SweepTypes ty = make_types(0, false);
-                run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st);
+                // with reuse on, the terms of the p column are kept: a Jacobian at this point then sweeps its tangent
+                // columns alone and a Hessian needs no forward sweep at all
+                const bool keep_p = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
+                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, st, keep_p);
                 b.cache_kind = h->reuse ? 1 : 0;
+                remember_p_terms(h, b, keep_p, steps, st);
             }
             launch_cons_bilinear(st, h->P, b.k, b.fw, dZ, dg);
         }
@@ -920,12 +937,25 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 if (same && b.cache_kind >= 2) return;  // the tangent sums of this very point are still in b.fw
                 SweepPlan plan = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);
                 SweepTypes ty = make_types(b.k.m, false);
+                if (same && b.p_terms && plan.q == 1) {
+                    // the p column of this very point is stored (eval_constraint or a Hessian came first): sweep the
+                    // tangent columns alone, their inhomogeneous terms read the stored p terms
+                    SweepBuf wf = b.fw;
+                    wf.frozen = b.fw.Zt;
+                    wf.frozen_total = b.p_steps + 1;
+                    wf.first_type = 1;
+                    run_sweep(h, b, wf, ty, dZ, nullptr, 0, 0, plan, ss, false);
+                    launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+                    b.cache_kind = 2;
+                    return;
+                }
                 // with reuse on and a Hessian to follow, keep every Taylor term so that the Hessian can skip its forward sweep
                 const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
                 const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep);
                 launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
+                if (keep || plan.q > 1) b.p_terms = false;  // the store now holds every column type / the scale factors changed
             }, [&] { if (lone) launch_jac_zero(st, h->P, b.k, dvals); });
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_join, ss));
@@ -964,17 +994,22 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 // sweep only the Taylor terms of the p column are used (k_hess_pair, k_hess_bilinear).
                 if (same && b.cache_kind == 3) {
                     steps_f = b.cache_steps;  // the Jacobian of this very point stored every forward term
+                } else if (same && b.p_terms) {
+                    Tf = 1;
+                    steps_f = b.p_steps;      // eval_constraint (or an earlier Hessian) stored the p terms of this point
                 } else {
                     Tf = 1;
                     steps_f = run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, plan, st, true);
                     b.cache_kind = h->reuse ? 1 : 0;  // the p sums are valid, the tangent sums are not
                     b.cache_steps = steps_f;
+                    remember_p_terms(h, b, true, steps_f, st);
                 }
                 launch_apply_generators(st, b.k, b.fw, 0, b.fw.Zt, b.fw.W);  // V_l = G_l x (term 0 of the p column is x)
             } else {
                 steps_f = run_sweep(h, b, b.fw, make_types(m, true), dZ, nullptr, 0, 0, plan, st, false);
                 launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = 0;
+                b.p_terms = false;  // this sweep re-initialised the scale factors for its own q
                 // W_j = G_j' mu from the adjoint sweep's term-0 buffer
                 launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
                 launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
@@ -989,7 +1024,9 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 const int nf = steps_f + 1, na = steps_a + 1;
                 const int64_t typesz = (int64_t)b.fw.Kpad * b.k.npad;
                 const int64_t cols = (int64_t)na * b.fw.Kpad;  // one type of every stored term
-                launch_pair_combine(st, b.fw, Tf, 1, na, nf, b.ad.nterms, b.d_Btab, b.Upair);
+                SweepBuf plain = b.fw;
+                if (Tf == 1) plain.nterms = b.fw.nterms_p;  // (a frozen Jacobian sweep in between re-used fw.nterms)
+                launch_pair_combine(st, plain, Tf, 1, na, nf, b.ad.nterms, b.d_Btab, b.Upair);
                 {
                     ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m);
                     launch_apply_generators_cols(st, b.k, b.fw, 0, b.Upair, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)Tf * typesz);
@@ -1517,6 +1554,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                         w->dcap = dcap;
                         w->nterms = own(h, dalloc<int32_t>(w->Kpad / w->TN));
                         HIP_CHECK(hipMemset(w->nterms, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
+                        w->nterms_p = own(h, dalloc<int32_t>(w->Kpad / w->TN));
+                        HIP_CHECK(hipMemset(w->nterms_p, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
                     }
                     b.EP = own(h, dalloc<double>((size_t)m * dcap * b.fw.Kpad * b.k.npad));  // G_j' U_a
                     b.Upair = own(h, dalloc<double>(store));
@@ -1769,6 +1808,7 @@ static void jac_product_matrix_free(dto_handle* h, const double* dZ, const doubl
     for (auto& b : h->bil) {
         if (h->P.n_int <= 0) continue;
         b.cache_kind = 0;  // the product sweeps use b.fw with their own column types
+        b.p_terms = false;
         SweepPlan plan = plan_from(h, b, dZ, st);
         SweepTypes ty = make_types(b.k.m, false);
         if (!transpose) {
@@ -1849,7 +1889,7 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
     if (!h || !name) return 1;
     if (std::string(name) == "reuse_forward_sweep") {
         h->reuse = value != 0;
-        for (auto& b : h->bil) b.cache_kind = 0;
+        for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
         return 0;
     }
     if (std::string(name) == "expm_form") {

@@ -179,6 +179,12 @@ struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear i
     double* Zt;
     int32_t dcap, T_alloc;  // T_alloc: column types the Z/S buffers were sized for
     int32_t* nterms;   // [Kpad/TN] number of valid terms of a converged column block (0: use all launched)
+    // option reuse_forward_sweep: the Taylor terms of the p column kept by an earlier callback at the same point
+    // ([dcap][Kpad][npad] at the head of Zt) let a later sweep run its tangent columns alone (types first_type..T-1)
+    int32_t* nterms_p;       // [Kpad/TN] valid stored p terms per column block (0: all frozen_total)
+    const double* frozen;    // stored p terms (nullptr: the sweep computes its own p column)
+    int32_t frozen_total;    // terms 0 .. frozen_total-1 were stored
+    int32_t first_type;      // first column type the sweep computes (1 with frozen p terms, else 0)
 };
 
 // src_kind: 0 = state x_k of the integrator (forward sweep), 1 = multipliers mu_k (adjoint sweep)
@@ -198,6 +204,8 @@ void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const d
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
                        int t, int in_buf, int split_store = 0);
 void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);
+// start of a sweep over types first_type..T-1 only: their terms, sums and norms are cleared, type 0 keeps its sums
+void launch_sweep_init_tangents(hipStream_t st, const SweepBuf& w, int T);
 // out[j] = G_j (or G_j') * V for every generator j (no summation): out [(m+1)][Kpad][npad]
 void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
                              double* out);

@@ -864,6 +864,33 @@ __global__ void __launch_bounds__(256) k_sweep_set_type(KProb P, KBil B, SweepBu
         w.sumnorm[(int64_t)type * w.Kpad + k] = dbits(mx);
     }
 }
+// Start of a sweep that computes types first_type..T-1 only (frozen p terms): clear their term-0 buffers, sums and norms;
+// type 0 keeps its sums (exp(A)x of the earlier callback) and counts as converged from the start.
+__global__ void __launch_bounds__(256) k_sweep_init_tangents(SweepBuf w, int T) {
+    const int k = blockIdx.x;
+    const int64_t colsz = w.npad;
+    for (int t = w.first_type; t < T; ++t)
+        for (int r = threadIdx.x; r < w.npad; r += blockDim.x) {
+            const int64_t off = ((int64_t)t * w.Kpad + k) * colsz + r;
+            w.Z[0][off] = 0.0;
+            w.S[off] = 0.0;
+        }
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < T; ++t) {
+            for (int sl = 0; sl < 3; ++sl) w.termnorm[((int64_t)sl * T + t) * w.Kpad + k] = 0ull;
+            if (t >= w.first_type) w.sumnorm[(int64_t)t * w.Kpad + k] = 0ull;
+        }
+        if (k % w.TN == 0) {
+            w.active[k / w.TN] = 1;
+            if (w.nterms) w.nterms[k / w.TN] = 0;
+        }
+        if (k == 0) { w.stats[0] = w.Kpad / w.TN; w.stats[1] = 0; }
+    }
+}
+void launch_sweep_init_tangents(hipStream_t st, const SweepBuf& w, int T) {
+    hipLaunchKernelGGL(k_sweep_init_tangents, dim3(w.Kpad), dim3(256), 0, st, w, T);
+}
+
 void launch_sweep_set_type(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, int T, int type, const double* v) {
     hipLaunchKernelGGL(k_sweep_set_type, dim3(w.Kpad), dim3(256), 0, st, P, B, w, T, type, v);
 }
@@ -970,7 +997,9 @@ __device__ __forceinline__ void sweep_epilogue(const SweepArgs& a, GemmAcc<TM, T
 // i.e. a GEMM whose K dimension is the concatenation of the generator blocks, the per-interval
 // bilinear coefficients being applied to the B panel while it is staged into LDS; an extra term shares the
 // segment of its generator (both right-hand sides are combined in the staging registers).
-template <int TM, int TN>
+// FROZEN: the p column is not computed -- its Taylor terms were stored by an earlier callback at the same point
+// (a.w.frozen); the workgroups cover types first_type..T-1 and take the inhomogeneous term from the store.
+template <int TM, int TN, bool FROZEN = false>
 __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(SweepArgs a) {
     using Cfg = GemmCfg<TM, TN>;
     __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
@@ -978,7 +1007,7 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
     const int row_tiles = npad / TM;
     const int rt = blockIdx.x % row_tiles;
     const int ct = blockIdx.x / row_tiles;
-    const int ty = blockIdx.y;  // column type (mode 0) or generator index (mode 1)
+    const int ty = blockIdx.y + (FROZEN ? a.w.first_type : 0);  // column type (mode 0) or generator index (mode 1)
     if ((a.mode == 0 || a.mode == 3) && !a.w.active[(ct * TN) / a.w.TN]) return;
     const int64_t nn = (int64_t)npad * npad;
     const int64_t typesz = (int64_t)Kpad * npad;
@@ -996,8 +1025,14 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
             int e = -1;
             for (int x = 0; x < td.n_extra; ++x)
                 if (td.gen[x] == j) e = x;
+            if (FROZEN && e >= 0 && td.src[e] == 0) {
+                // stored p term t; beyond the block's stored terms the p series had converged: nothing to add
+                const int cnt = a.w.nterms_p[(ct * TN) / a.w.TN];
+                if (a.t >= (cnt > 0 ? cnt : a.w.frozen_total)) e = -1;
+            }
             if (e >= 0) {
-                const double* Bs = a.Zin + td.src[e] * typesz + (int64_t)ct * TN * npad;
+                const double* Bs = (FROZEN && td.src[e] == 0 ? a.w.frozen + (int64_t)a.t * typesz : a.Zin + td.src[e] * typesz) +
+                                   (int64_t)ct * TN * npad;
                 // scaleE[0] carries dt/q, scaleE[1] carries 2 dt/q (the i == j second-order terms)
                 gemm_accumulate2<TM, TN>(acc, a.G + j * nn + (int64_t)rt * TM, npad, Bt, npad, npad,
                                          a.w.scaleA + (int64_t)j * Kpad + ct * TN, Bs,
@@ -1041,6 +1076,14 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
     if (!relax && (npad % 128 != 0 || a.w.TN != 128)) choice = 0;
     if ((choice == 3 || choice == 1) && npad % 128 != 0) choice = 0;  // 128-row tiles need npad % 128 == 0
     if ((choice == 3 || choice == 2) && a.w.Kpad % 128 != 0) choice = 0;
+    if (a.mode == 0 && a.w.frozen) {
+        if (choice != 6) choice = 5;
+        if (choice == 6)
+            hipLaunchKernelGGL((k_sweep<32, 32, true>), dim3((npad / 32) * (a.w.Kpad / 32), ny), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_sweep<64, 32, true>), dim3((npad / 64) * (a.w.Kpad / 32), ny), dim3(256), 0, st, a);
+        return;
+    }
     switch (choice) {
         case 3:
             hipLaunchKernelGGL((k_sweep<128, 128>), dim3((npad / 128) * (a.w.Kpad / 128), ny), dim3(256), 0, st, a);
@@ -1119,7 +1162,7 @@ void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const S
     // (a variant that keeps one accumulator tile per column TYPE in each wave -- generator panels reused by all types,
     // term chunks by all generators, coefficients applied in registers: ~6x less L2->LDS traffic -- was measured 7 %
     // slower at 256x2000: with 512 workgroups of 80 short barrier-separated steps it has less slack than this one)
-    launch_sweep_kernel(st, a, ty.T);
+    launch_sweep_kernel(st, a, ty.T - (w.frozen ? w.first_type : 0));
 }
 void launch_apply_generators(hipStream_t st, const KBil& B, const SweepBuf& w, int transposed, const double* V,
                              double* out) {

@@ -231,7 +231,8 @@ int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const do
  *   "reuse_forward_sweep" (default 0): interior-point solvers evaluate g, J and H at the same point one after the
  *   other.  With this on, the engine remembers the forward generator sweep of the last callback and re-uses it when
  *   the next callback's Z is bit-identical (compared on the device, one 4-byte readback): eval_constraint after
- *   eval_jacobian then costs a copy, eval_hessian skips its forward sweep.  Results agree to rounding either way (the constraint-only
+ *   eval_jacobian then costs a copy, eval_jacobian after eval_constraint sweeps its tangent columns only, eval_hessian
+ *   skips its forward sweep.  Results agree to rounding either way (the constraint-only
  *   sweep sums its generator products in a different order than the Jacobian's); the benchmark never turns it on (each
  *   callback is timed cold). */
 /*   "expm_form" (default 0): evaluation form of the matrix-exponential polynomial in eval_constraint_jacobian.  0 picks per
