@@ -186,6 +186,12 @@ struct dto_handle {
     std::vector<hipEvent_t> ev_pool;  // recycled timing events (creating them inside the timed region costs host time)
     int last_smax = 0, last_terms = 0;
     int expm_form = 0;  // option "expm_form": 0 = by cost, 2 / 3 = forced
+    int chain_chunk = 0;  // option "chain_chunk": upper bound on the intervals per chain chunk (0: workspace capacity)
+    // deferred errors of the `*_dev` entry points (dto_engine.h, error convention): the sweep statistics of the last
+    // asynchronous call are copied to pinned memory behind its kernels and looked at by the next call through the ABI
+    hipEvent_t ev_done = nullptr;
+    bool stats_pending = false;
+    int32_t* h_stats = nullptr;  // pinned [2 * bilinear integrators][2]
     int last_form = 0;
     std::vector<void*> owned;  // device allocations to free
 
@@ -208,6 +214,8 @@ dto_handle::~dto_handle() {
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_stats) (void)hipEventDestroy(ev_stats);
     if (ev_chain) (void)hipEventDestroy(ev_chain);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (h_stats) (void)hipHostFree(h_stats);
 }
 
 namespace {
@@ -439,7 +447,7 @@ SweepPlan plan_sweep(double beta) {
         p.q = 1; p.d_ub = 30;
         return p;
     }
-    static const double theta_v = [] { const char* e = getenv("DTO_THETA_V"); return e ? atof(e) : 9.0; }();  // worst-case cancellation budget e^9 ~ 1e4 on the Taylor sums (tolerance 1e-10)
+    static const double theta_v = tune_double("DTO_THETA_V", 9.0);  // worst-case cancellation budget e^9 ~ 1e4 on the Taylor sums (tolerance 1e-10)
     p.q = std::max(1, (int)std::ceil(beta / theta_v));
     const double br = beta / p.q;
     int t = 8;
@@ -480,7 +488,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
         // an upper bound on the terms needed at this very Z, so tc is a function of Z alone and results stay reproducible;
         // a column block that would pass earlier merely adds a few terms below 1e-16 of its sum).  Each test left out is one
         // kernel and one dependent-launch gap less (~12 us).  The term-norm slots the tests recycle are cleared once instead.
-        static const int tc_env = [] { const char* e = getenv("DTO_SWEEP_TC"); return e ? atoi(e) : -1; }();
+        static const int tc_env = tune_int("DTO_SWEEP_TC", -1);
         int tc = tc_env >= 0 ? tc_env : plan.d_ub / 2 - 1;
         if (tc < 2) tc = 0;
         for (int t = 0; t < plan.d_ub; ++t) {
@@ -618,11 +626,7 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
 }
 
 int chunk_size(const dto_handle* h, int npad) {
-    // workspace budget for the 9 chain matrices; DTO_CHAIN_CHUNK overrides
-    if (const char* e = getenv("DTO_CHAIN_CHUNK")) {
-        int v = atoi(e);
-        if (v > 0) return v;
-    }
+    // workspace budget for the 9 chain matrices (option "chain_chunk" lowers the chunk per call)
     const double budget = 36e9;
     int c = (int)(budget / (9.0 * npad * (double)npad * 8.0));
     c = std::max(8, (c / 8) * 8);
@@ -640,7 +644,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     const int64_t nint = h->P.n_int;
     double d2max = 0.0;
     if (nint <= 0) return d2max;
-    const int cap = b.chain_cap;
+    const int cap = h->chain_chunk > 0 ? std::min(h->chain_chunk, b.chain_cap) : b.chain_cap;
     int s_ub = 1;
     if (b1max == b1max && b1max > THETA_16) s_ub = std::isinf(b1max) ? 60 : std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
     s_ub = std::min(s_ub, 60);
@@ -690,7 +694,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         // outputs, five epilogue streams: HBM-bound) costs about 1.5 squarings (measured at 256x2000: 1.63 ms against 1.29 ms
         // per launch, and 2 x 1.50 ms for the two products of the other form)
         int form = 2 * ((int64_t)hs[1] - (int64_t)hs[5]) > 3 * (int64_t)nb ? 3 : 2;
-        static const int env_form = [] { const char* e = getenv("DTO_EXPM_FORM"); return e ? atoi(e) : 0; }();  // A/B runs
+        static const int env_form = tune_int("DTO_EXPM_FORM", 0);  // A/B runs
         if (env_form == 2 || env_form == 3) form = env_form;
         if (h->expm_form == 2 || h->expm_form == 3) form = h->expm_form;
         h->last_form = form;
@@ -797,8 +801,8 @@ void read_hump(dto_handle* h, BilHost& b) {
     }
 }
 SweepPlan plan_hump(const BilHost& b, double beta_fallback) {
-    static const double theta_v = [] { const char* e = getenv("DTO_THETA_V"); return e ? atof(e) : 9.0; }();
-    static const bool on = [] { const char* e = getenv("DTO_HUMP_PLAN"); return !e || atoi(e) != 0; }();
+    static const double theta_v = tune_double("DTO_THETA_V", 9.0);
+    static const bool on = tune_int("DTO_HUMP_PLAN", 1) != 0;
     if (on && b.hump_valid)
         for (int q = 1; q <= 4; ++q)
             if (b.hump_logH[q - 1] <= theta_v) return SweepPlan{q, std::min(200, b.hump_kend[q - 1] + 6)};
@@ -880,7 +884,7 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
     const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
         if (b.small) {
-            launch_small(st, h->P, b.k, b.d_Gs, make_types(0, false), make_types(0, false), dZ, nullptr, dg, nullptr, nullptr, 1);
+            HIP_CHECK(launch_small(st, h->P, b.k, b.d_Gs, make_types(0, false), make_types(0, false), dZ, nullptr, dg, nullptr, nullptr, 1));
             continue;
         }
         if (h->P.n_int > 0) {
@@ -916,7 +920,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
     const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
         if (b.small) {
-            launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, false), make_types(0, false), dZ, nullptr, nullptr, dvals, nullptr, 2);
+            HIP_CHECK(launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, false), make_types(0, false), dZ, nullptr, nullptr, dvals, nullptr, 2));
             continue;
         }
         Bounds bd{0, 0};
@@ -924,7 +928,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
             // generator-norm bounds: enqueued here, read inside the chain's own readback point (no stream sync of their
             // own); the squaring cap they used to provide is the constant 60, a NaN iterate gets one squaring
             enqueue_bounds(h, b, dZ, st);
-            static const bool overlap = [] { const char* e = getenv("DTO_OVERLAP"); return e && atoi(e) != 0; }();  // off by default: +2% end to end, but per-kernel timings blur
+            static const bool overlap = tune_int("DTO_OVERLAP", 0) != 0;  // off by default: +2% end to end, but per-kernel timings blur
             hipStream_t ss = overlap ? h->stream2 : st;
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
@@ -982,7 +986,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             BilHost& b = h->bil[h->integ_index[i]];
             if (h->P.n_int <= 0) continue;
             if (b.small) {
-                launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, true), make_types(b.k.m, false), dZ, dmu, nullptr, nullptr, dH, 4);
+                HIP_CHECK(launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, true), make_types(b.k.m, false), dZ, dmu, nullptr, nullptr, dH, 4));
                 continue;
             }
             SweepPlan plan = plan_from(h, b, dZ, st);
@@ -1060,38 +1064,79 @@ double* staging(dto_handle* h, size_t n) {
     return h->d_out;
 }
 
+void drop_caches(dto_handle* h) {
+    for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
+}
+
+// Enqueue, behind the kernels of an asynchronous call, the copy of every sweep's statistics to pinned memory.
+void enqueue_stats(dto_handle* h, hipStream_t st) {
+    if (!h->h_stats) return;
+    size_t i = 0;
+    bool any = false;
+    for (auto& b : h->bil)
+        for (SweepBuf* w : {&b.fw, &b.ad}) {
+            if (w->stats) {
+                HIP_CHECK(hipMemcpyAsync(h->h_stats + 2 * i, w->stats, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                any = true;
+            }
+            ++i;
+        }
+    if (!any) return;
+    HIP_CHECK(hipEventRecord(h->ev_done, st));
+    h->stats_pending = true;
+}
+// Look at the statistics of the last call (waits for them): a sweep that ran out of its step budget is an error.
+void check_sweeps(dto_handle* h) {
+    if (!h->stats_pending) return;
+    h->stats_pending = false;
+    HIP_CHECK(hipEventSynchronize(h->ev_done));
+    size_t i = 0;
+    bool bad = false;
+    for (auto& b : h->bil)
+        for (SweepBuf* w : {&b.fw, &b.ad}) {
+            if (w->stats) {
+                h->last_terms = std::max(h->last_terms, h->h_stats[2 * i + 1]);
+                if (h->h_stats[2 * i] != 0) bad = true;
+            }
+            ++i;
+        }
+    if (bad) {
+        drop_caches(h);  // whatever the sweeps left behind is not a converged result
+        throw HipError{"generator sweep did not converge within its step budget"};
+    }
+}
+
+// Every entry point that evaluates runs through here.  ASYNC: device-pointer form on stream `st` -- device-side errors are
+// reported by the NEXT call (check_sweeps at entry); BLOCKING: host-pointer form, checked before it returns; PLAIN: no sweeps.
+enum { G_PLAIN = 0, G_ASYNC = 1, G_BLOCKING = 2 };
 template <class F>
-int guarded(dto_handle* h, F&& f) {
+int guarded(dto_handle* h, F&& f, int mode = G_PLAIN, hipStream_t st = nullptr) {
     if (!h) return fail(nullptr, "null handle");
     if (h->structure_only) return fail(h, "structure-only handle (created with device < 0): no evaluation without a GPU");
     try {
         HIP_CHECK(hipSetDevice(h->device));
+        check_sweeps(h);            // deferred error of the previous asynchronous call, if any
+        (void)hipGetLastError();    // the launches below are judged on their own
         f();
+        // kernel launches report a rejected configuration through the runtime's last-error slot, not a return value
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) throw HipError{std::string("kernel launch failed: ") + hipGetErrorString(le)};
+        if (mode == G_BLOCKING) { enqueue_stats(h, h->stream); check_sweeps(h); }
+        else if (mode == G_ASYNC) enqueue_stats(h, st);
         return 0;
     } catch (const HipError& e) {
+        drop_caches(h);
+        h->stats_pending = false;
         return fail(h, e.msg);
     } catch (const std::exception& e) {
+        drop_caches(h);
+        h->stats_pending = false;
         return fail(h, e.what());
     }
 }
 
 void upload_Z(dto_handle* h, const double* Z) {
     HIP_CHECK(hipMemcpyAsync(h->d_Z, Z, sizeof(double) * (size_t)h->n_vars, hipMemcpyHostToDevice, h->stream));
-}
-
-void check_sweeps(dto_handle* h) {
-    // after a synchronised call: the Taylor recurrences must have terminated inside their step budget
-    for (auto& b : h->bil) {
-        if (b.small) continue;
-        for (SweepBuf* w : {&b.fw, &b.ad}) {
-            if (!w->stats) continue;
-            int32_t st[2];
-            HIP_CHECK(hipMemcpy(st, w->stats, sizeof(st), hipMemcpyDeviceToHost));
-            h->last_terms = std::max(h->last_terms, st[1]);
-            if (st[0] != 0) throw HipError{"generator sweep did not converge within its step budget"};
-        }
-    }
-
 }
 
 }  // namespace
@@ -1135,6 +1180,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;
@@ -1177,12 +1223,14 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 if (!sonly) {
                     b.k.G = own(h, dupload(G));
                     b.k.GT = own(h, dupload(GT));
-                    static const bool small_on = [] { const char* e = getenv("DTO_SMALL_N"); return !e || atoi(e) != 0; }();
+                    const bool small_on = (d->flags & DTO_FLAG_GENERAL_PATH_ONLY) == 0;
                     // fused one-workgroup-per-interval path: n <= 16 with one wavefront, 17..32 with four, while the
                     // interval's matrices, generators and sweep columns fit the CU's LDS
                     const int mm_ = s.u_dim, Tf = d->eval_hessian ? 1 + mm_ + mm_ * (mm_ + 1) / 2 : 1 + mm_;
                     if (small_on && n <= 32 && Tf <= MAX_TYPES && small_lds_bytes(n, mm_, Tf, 1 + mm_) <= 150 * 1024) {
                         b.small = true;
+                        // worst-case dynamic LDS of this handle's fused kernel, opted into on THIS device
+                        HIP_CHECK(small_prepare(small_lds_bytes(n, mm_, Tf, 1 + mm_)));
                         b.d_Gs = own(h, dupload(std::vector<double>(s.G, s.G + (size_t)m1 * n * n)));
                     }
                 }
@@ -1527,6 +1575,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         h->d_f = own(h, dalloc<double>(1));
         h->d_bounds = own(h, dalloc<double>(2));
         HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 32 * sizeof(double)));
+        HIP_CHECK(hipHostMalloc((void**)&h->h_stats, sizeof(int32_t) * 4 * std::max<size_t>(h->bil.size(), 1)));
+        memset(h->h_stats, 0, sizeof(int32_t) * 4 * std::max<size_t>(h->bil.size(), 1));
 
         // per-bilinear workspaces + generator product norms (for the step-budget bounds)
         for (auto& b : h->bil) {
@@ -1544,7 +1594,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 // would take more than 40 % of the free HBM: the second-order sweep is then used)
                 const int dcap = 64, T1 = 1 + m;
                 const double bytes = (double)dcap * T1 * b.fw.Kpad * b.k.npad * 8.0;
-                static const bool pair_on = [] { const char* e = getenv("DTO_HESS_PAIRING"); return !e || atoi(e) != 0; }();
+                static const bool pair_on = tune_int("DTO_HESS_PAIRING", 1) != 0;
                 size_t free_b = 0, total_b = 0;
                 HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
                 if (pair_on && m >= 1 && bytes * (3.0 + 1.0 * m / T1) < 0.4 * (double)free_b) {
@@ -1594,7 +1644,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 // (npad is a multiple of 64: npad^2 is a multiple of the kernel's 128-row tiles and every wave's 64 rows of
                 // vec(A^r) stay inside one matrix column, which is all k_basis_gemm's fused column sums need)
                 bool want = cnt * 2 <= 3L * npad;
-                if (const char* e = getenv("DTO_BASIS_POWERS")) want = atoi(e) != 0;
+                { const int f = tune_int("DTO_BASIS_POWERS", -1); if (f >= 0) want = f != 0; }
                 if (want) build_basis(h, b, b.chain_cap);
             }
         }
@@ -1737,16 +1787,16 @@ int dto_eval_gradient_dev(dto_handle* h, const double* dZ, double* dgrad, void* 
     return guarded(h, [&] { do_gradient(h, dZ, dgrad, (hipStream_t)stream); });
 }
 int dto_eval_constraint_dev(dto_handle* h, const double* dZ, double* dg, void* stream) {
-    return guarded(h, [&] { do_constraint(h, dZ, dg, (hipStream_t)stream); });
+    return guarded(h, [&] { do_constraint(h, dZ, dg, (hipStream_t)stream); }, G_ASYNC, (hipStream_t)stream);
 }
 int dto_eval_jacobian_dev(dto_handle* h, const double* dZ, double* dvals, void* stream) {
-    return guarded(h, [&] { do_jacobian(h, dZ, dvals, (hipStream_t)stream); });
+    return guarded(h, [&] { do_jacobian(h, dZ, dvals, (hipStream_t)stream); }, G_ASYNC, (hipStream_t)stream);
 }
 int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dvals, void* stream) {
     return guarded(h, [&] {
         if (!h->eval_hessian) throw HipError{"handle was created with eval_hessian = 0"};
         do_hessian(h, dZ, sigma, dmu, dvals, (hipStream_t)stream);
-    });
+    }, G_ASYNC, (hipStream_t)stream);
 }
 
 // ---- host-pointer callbacks (blocking)
@@ -1774,8 +1824,7 @@ int dto_eval_constraint(dto_handle* h, const double* Z, double* g) {
         do_constraint(h, h->d_Z, o, h->stream);
         HIP_CHECK(hipMemcpyAsync(g, o, sizeof(double) * (size_t)h->cons_len, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
-        check_sweeps(h);
-    });
+    }, G_BLOCKING);
 }
 int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals) {
     return guarded(h, [&] {
@@ -1784,8 +1833,7 @@ int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals) {
         do_jacobian(h, h->d_Z, o, h->stream);
         HIP_CHECK(hipMemcpyAsync(vals, o, sizeof(double) * (size_t)h->info.jac_len, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
-        check_sweeps(h);
-    });
+    }, G_BLOCKING);
 }
 int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double* mu, double* vals) {
     return guarded(h, [&] {
@@ -1796,8 +1844,7 @@ int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double*
         do_hessian(h, h->d_Z, sigma, h->d_mu, o, h->stream);
         HIP_CHECK(hipMemcpyAsync(vals, o, sizeof(double) * (size_t)h->info.hess_len, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
-        check_sweeps(h);
-    });
+    }, G_BLOCKING);
 }
 
 // Matrix-free products for handles whose bilinear integrators all take the general path: exp(A)w_x rides the
@@ -1837,7 +1884,7 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
     for (auto& b : h->bil) mfree = mfree && !b.small && (transpose == 0 || b.ad.S != nullptr) && b.k.m + 2 <= MAX_TYPES;
     for (auto& c : h->con) mfree = mfree && !c.external;  // external blocks are placed into the value slab
     mfree = mfree && h->ext_int.empty();
-    static const bool mfree_on = [] { const char* e = getenv("DTO_JV_MATRIX_FREE"); return !e || atoi(e) != 0; }();
+    static const bool mfree_on = tune_int("DTO_JV_MATRIX_FREE", 1) != 0;
     if (mfree && mfree_on) {
         const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;
         if (!h->d_w) h->d_w = own(h, dalloc<double>((size_t)std::max(h->n_vars, h->n_cons)));
@@ -1847,7 +1894,6 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
         jac_product_matrix_free(h, h->d_Z, h->d_w, o, transpose, h->stream);
         HIP_CHECK(hipMemcpyAsync(y, o, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
-        check_sweeps(h);
         return;
     }
     if (h->integ_kind.size() > 8) throw HipError{"Jacobian-vector products support at most 8 integrators"};
@@ -1873,15 +1919,14 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
         launch_jac_spmv(h->stream, h->P, T, h->d_conbase, h->d_con_rows, h->d_jac_scratch, h->d_w, o, transpose, h->gd);
     HIP_CHECK(hipMemcpyAsync(y, o, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    check_sweeps(h);
 }
 // y = J(Z) w  -- MOI.eval_constraint_jacobian_product (evaluator.jl:406-430)
 int dto_eval_jacobian_product(dto_handle* h, const double* Z, const double* w, double* y) {
-    return guarded(h, [&] { jac_product(h, Z, w, y, 0); });
+    return guarded(h, [&] { jac_product(h, Z, w, y, 0); }, G_BLOCKING);
 }
 // y = J(Z)' w -- MOI.eval_constraint_jacobian_transpose_product (evaluator.jl:432-456)
 int dto_eval_jacobian_transpose_product(dto_handle* h, const double* Z, const double* w, double* y) {
-    return guarded(h, [&] { jac_product(h, Z, w, y, 1); });
+    return guarded(h, [&] { jac_product(h, Z, w, y, 1); }, G_BLOCKING);
 }
 
 // ---- measurement
@@ -1889,7 +1934,16 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
     if (!h || !name) return 1;
     if (std::string(name) == "reuse_forward_sweep") {
         h->reuse = value != 0;
-        for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
+        drop_caches(h);
+        return 0;
+    }
+    if (std::string(name) == "chain_chunk") {
+        if (value < 0) return fail(h, "dto_set_option: chain_chunk must be >= 0");
+        h->chain_chunk = (int)std::min<int64_t>(value, 1 << 30);
+        return 0;
+    }
+    if (std::string(name) == "debug_bad_launch") {
+        h->P.debug_bad_launch = value != 0;
         return 0;
     }
     if (std::string(name) == "expm_form") {
@@ -1948,7 +2002,9 @@ int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launch
 int dto_last_stats(const dto_handle* h, int32_t* max_squarings, int32_t* expmv_terms) {
     if (!h) return 1;
     dto_handle* hm = const_cast<dto_handle*>(h);
-    int rc = guarded(hm, [&] { HIP_CHECK(hipDeviceSynchronize()); check_sweeps(hm); });
+    // the deferred error of an asynchronous call surfaces here (guarded looks at the pending statistics first); the
+    // statistics themselves are then read again so that `expmv_terms` is current after blocking calls as well
+    int rc = guarded(hm, [&] { HIP_CHECK(hipDeviceSynchronize()); }, G_BLOCKING);
     if (max_squarings) *max_squarings = h->last_smax;
     if (expmv_terms) *expmv_terms = h->last_terms;
     return rc;

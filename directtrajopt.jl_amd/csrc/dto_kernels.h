@@ -4,7 +4,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace dto {
+
+// Tuning switches for A/B measurements exist only in builds with -DDTO_TUNING (`make TUNING=1`); the product
+// library reads no environment variable.
+inline int tune_int(const char* name, int dflt) {
+#ifdef DTO_TUNING
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+inline double tune_double(const char* name, double dflt) {
+#ifdef DTO_TUNING
+    const char* e = getenv(name);
+    return e ? atof(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 constexpr int TAYLOR_M = 16;                 // degree of the matrix Taylor polynomial
 constexpr double THETA_16 = 0.78028743;      // backward-error radius of T_16 in double (Al-Mohy & Higham 2011, Table 3.1 method)
@@ -45,7 +68,7 @@ struct KProb {
     int64_t N, K;       // knots, intervals (K = N-1)
     int32_t z, dt_idx;  // components per knot, timestep component
     int32_t D;          // sum of integrator state dims (Jacobian rows per interval)
-    int32_t pad0;
+    int32_t debug_bad_launch;  // option "debug_bad_launch" (tests of the error path): launches are given an invalid configuration
     int64_t kn_lo;      // first owned knot (0-based)
     int64_t n_knots;    // owned knots
     int64_t n_int;      // owned intervals: knots kn_lo .. kn_lo+n_int-1 (each < K)
@@ -303,9 +326,10 @@ void launch_fill(hipStream_t st, double* p, int64_t n, double v);
 // Small-state path (dto_small.hip): one wavefront per interval, everything in LDS.  mode bits: 1 constraint
 // values, 2 Jacobian block, 4 Hessian block.  Gs = compact (m+1) x n x n generators.
 size_t small_lds_bytes(int n, int m, int T_fw, int T_ad);
-void launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* Gs, const SweepTypes& ty_fw,
-                  const SweepTypes& ty_ad, const double* dZ, const double* dmu, double* cons, double* jac, double* hess,
-                  int mode);
+hipError_t small_prepare(size_t lds_bytes);  // per-device opt-in to > 64 KB of dynamic LDS (dto_create)
+hipError_t launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* Gs, const SweepTypes& ty_fw,
+                        const SweepTypes& ty_ad, const double* dZ, const double* dmu, double* cons, double* jac, double* hess,
+                        int mode);
 
 // y = J w / y = J' w from the value slab in CSC order (A3: evaluator.jl:406-456; the reference also
 // materialises the Jacobian values first, on the host).  One wavefront per column.

@@ -31,6 +31,10 @@ __device__ __forceinline__ double bits_to_d(unsigned long long b) { return __lon
 
 __device__ __forceinline__ void hess_add(const KProb& P, double* H, int64_t kn, int a, int b, double v);
 
+// block size of the assembly kernels; option "debug_bad_launch" asks for one the hardware does not have, so that the
+// tests can see a rejected launch come back through the C ABI as an error
+static inline dim3 blk(const KProb& P, int threads) { return dim3(P.debug_bad_launch ? 4096 : threads); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(256) k_jac_zero(KProb P, KBil B, double* __res
 void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals) {
     if (P.n_knots <= 0) return;
     int gy = P.z < 32 ? P.z : 32;
-    hipLaunchKernelGGL(k_jac_zero, dim3((unsigned)P.n_knots, gy), dim3(256), 0, st, P, B, vals);
+    hipLaunchKernelGGL(k_jac_zero, dim3((unsigned)P.n_knots, gy), blk(P, 256), 0, st, P, B, vals);
 }
 
 __global__ void k_norm_bounds(KProb P, KBil B, const double* __restrict__ Z, const double* __restrict__ g1,
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__(256) k_build_A(KProb P, KBil B, const double* 
 void launch_build_A(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, int64_t int0, int nb, double* A) {
     const int64_t nn2 = (int64_t)B.npad * B.npad / 2;
     int gx = (int)((nn2 + 255) / 256);
-    static const int cap = [] { const char* e = getenv("DTO_BUILDA_GX"); return e ? atoi(e) : 16; }();
+    static const int cap = tune_int("DTO_BUILDA_GX", 16);
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(k_build_A, dim3(gx, nb), dim3(256), 0, st, P, B, dZ, int0, A);
 }
@@ -483,15 +487,15 @@ k_bgemm(BGemmArgs a) {
 }
 
 static int bgemm_shape_choice() {
-    static int v = [] { const char* e = getenv("DTO_BGEMM_SHAPE"); return e ? atoi(e) : -1; }();
+    static int v = tune_int("DTO_BGEMM_SHAPE", -1);
     return v;
 }
 static int bgemm_dma_choice() {  // -1: per-epilogue default, 0/1: forced
-    static int v = [] { const char* e = getenv("DTO_BGEMM_DMA"); return e ? atoi(e) : -1; }();
+    static int v = tune_int("DTO_BGEMM_DMA", -1);
     return v;
 }
 static int bgemm_wgs_choice() {  // -1: per-epilogue default, 0: one workgroup per tile, k: k persistent workgroups per CU
-    static int v = [] { const char* e = getenv("DTO_BGEMM_WGS_PER_CU"); return e ? atoi(e) : -1; }();
+    static int v = tune_int("DTO_BGEMM_WGS_PER_CU", -1);
     return v;
 }
 // Measured in the engine at 256x2000 (ms per launch, fused-polynomial / squaring):
@@ -521,7 +525,7 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
     // 128x128 tiles (persistent, DMA-staged) win once the launch is large; short trajectories are better served by four
     // times as many 64x64 workgroups.  Measured crossover (tile-128 workgroups x K panels): 256x200 -17 % with 64-tiles,
     // 256x500 equal, 256x1000 and 512x100 +5..7 % with 128-tiles (DTO_BGEMM_TILE64=0/1 forces).
-    static const int force64 = [] { const char* e = getenv("DTO_BGEMM_TILE64"); return e ? atoi(e) : -1; }();
+    static const int force64 = tune_int("DTO_BGEMM_TILE64", -1);
     const long t128 = a.npad / 128;
     const bool small_launch = force64 >= 0 ? force64 != 0 : t128 * t128 * t128 * a.nbatch < 3500;
     if (a.npad % 128 == 0 && small_launch && bgemm_shape_choice() < 0) {
@@ -1059,7 +1063,7 @@ __global__ void __launch_bounds__(256, (TM * TN <= 64 * 64 ? 4 : 2)) k_sweep(Swe
 }
 
 static int sweep_tile_choice() {
-    static int v = [] { const char* e = getenv("DTO_SWEEP_TILE"); return e ? atoi(e) : -1; }();
+    static int v = tune_int("DTO_SWEEP_TILE", -1);
     return v;
 }
 static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
@@ -1072,7 +1076,7 @@ static void launch_sweep_kernel(hipStream_t st, const SweepArgs& a, int ny) {
         const long wgs = (long)(npad / 64) * (a.w.Kpad / 32) * ny;
         choice = wgs >= 1024 ? 5 : 6;
     }
-    static const bool relax = [] { const char* e = getenv("DTO_SWEEP_TILE_RELAX"); return !e || atoi(e) != 0; }();
+    static const bool relax = tune_int("DTO_SWEEP_TILE_RELAX", 1) != 0;
     if (!relax && (npad % 128 != 0 || a.w.TN != 128)) choice = 0;
     if ((choice == 3 || choice == 1) && npad % 128 != 0) choice = 0;  // 128-row tiles need npad % 128 == 0
     if ((choice == 3 || choice == 2) && a.w.Kpad % 128 != 0) choice = 0;
@@ -1150,7 +1154,7 @@ void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const S
     a.Zin = w.Z[in_buf]; a.Zout = w.Z[in_buf ^ 1]; a.t = t; a.mode = 0;
     // a single column type (eval_constraint) offers few tiles with a long K loop each: split K by generator into the
     // unused type slots of the output buffer, then sum the partials (DTO_SWEEP_SPLITK=0 disables)
-    static const bool splitk = [] { const char* e = getenv("DTO_SWEEP_SPLITK"); return !e || atoi(e) != 0; }();
+    static const bool splitk = tune_int("DTO_SWEEP_SPLITK", 1) != 0;
     // (store mode with one type: the slots of the NEXT m+1 terms serve as scratch -- the caller vouches for the room)
     if (splitk && ty.T == 1 && B.m >= 1 && (split_store || (w.T_alloc >= B.m + 2 && w.Z[0] != w.Zt && a.Zin != w.Zt))) {
         const int64_t typesz = (int64_t)w.Kpad * w.npad;
@@ -1350,7 +1354,7 @@ __global__ void k_cons_bilinear(KProb P, KBil B, SweepBuf w, const double* __res
 void launch_cons_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const double* dZ, double* g) {
     const int64_t n = P.n_int * B.n;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_cons_bilinear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, B, w, dZ, g);
+    hipLaunchKernelGGL(k_cons_bilinear, dim3((unsigned)((n + 255) / 256)), blk(P, 256), 0, st, P, B, w, dZ, g);
 }
 
 // delta_k = x_{k+1} - x_k - dt_k xdot_k   (derivative_integrator.jl:55-64)
@@ -1366,7 +1370,7 @@ __global__ void k_cons_derivative(KProb P, KDer D, const double* __restrict__ Z,
 void launch_cons_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dZ, double* g) {
     const int64_t n = P.n_int * Dv.d;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_cons_derivative, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, Dv, dZ, g);
+    hipLaunchKernelGGL(k_cons_derivative, dim3((unsigned)((n + 255) / 256)), blk(P, 256), 0, st, P, Dv, dZ, g);
 }
 
 __device__ __forceinline__ double knot_norm2(const KProb& P, const KCon& C, const double* zk) {
@@ -1419,7 +1423,7 @@ __global__ void __launch_bounds__(256) k_jac_bilinear(KProb P, KBil B, SweepBuf 
 }
 void launch_jac_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, double* vals) {
     if (P.n_knots <= 0) return;
-    hipLaunchKernelGGL(k_jac_bilinear, dim3((unsigned)P.n_knots), dim3(256), 0, st, P, B, w, vals);
+    hipLaunchKernelGGL(k_jac_bilinear, dim3((unsigned)P.n_knots), blk(P, 256), 0, st, P, B, w, vals);
 }
 
 // DerivativeIntegrator block: d/dx_k = -I, d/dxdot_k = -dt I, d/ddt = -xdot_k, d/dx_{k+1} = I
@@ -1442,7 +1446,7 @@ __global__ void k_jac_derivative(KProb P, KDer D, const double* __restrict__ Z, 
 void launch_jac_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dZ, double* vals) {
     const int64_t n = P.n_knots * Dv.d;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_jac_derivative, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, Dv, dZ, vals);
+    hipLaunchKernelGGL(k_jac_derivative, dim3((unsigned)((n + 255) / 256)), blk(P, 256), 0, st, P, Dv, dZ, vals);
 }
 
 // dg/dv at the listed knots (knot_point_constraint.jl:254-268); entries outside the pattern taken
@@ -1765,7 +1769,7 @@ __global__ void k_hess_derivative(KProb P, KDer D, const double* __restrict__ mu
 void launch_hess_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dmu, double* H) {
     const int64_t n = P.n_int * Dv.d;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_hess_derivative, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, Dv, dmu, H);
+    hipLaunchKernelGGL(k_hess_derivative, dim3((unsigned)((n + 255) / 256)), blk(P, 256), 0, st, P, Dv, dmu, H);
 }
 
 // mu_i' * Hessian of g   (knot_point_constraint.jl:275-294), upper triangle of the comps x comps block
@@ -2019,7 +2023,7 @@ __global__ void __launch_bounds__(256) k_hess_bilinear(KProb P, KBil B, SweepBuf
 void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad,
                           const double* dmu, double* H, int with_uu) {
     if (P.n_int <= 0) return;
-    hipLaunchKernelGGL(k_hess_bilinear, dim3((unsigned)P.n_int), dim3(256), 0, st, P, B, fw, ad, dmu, H, with_uu);
+    hipLaunchKernelGGL(k_hess_bilinear, dim3((unsigned)P.n_int), blk(P, 256), 0, st, P, B, fw, ad, dmu, H, with_uu);
 }
 
 }  // namespace dto

@@ -325,36 +325,33 @@ __global__ void k_small_identity(KProb P, KBil B, double* __restrict__ jac) {
     if (kn >= 1) jac[jac_pos(P, P.colptr, kn, B.x_off + r, B.pre, B.n, 0, r)] = 1.0;
 }
 
-void launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* Gs, const SweepTypes& ty_fw,
-                  const SweepTypes& ty_ad, const double* dZ, const double* dmu, double* cons, double* jac, double* hess,
-                  int mode) {
+// Dynamic LDS beyond 64 KB has to be opted into per kernel and per DEVICE: called from dto_create (after
+// hipSetDevice) with the handle's worst-case request, so that no launch depends on what another handle did.
+hipError_t small_prepare(size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_small(hipStream_t st, const KProb& P, const KBil& B, const double* Gs, const SweepTypes& ty_fw,
+                        const SweepTypes& ty_ad, const double* dZ, const double* dmu, double* cons, double* jac, double* hess,
+                        int mode) {
     if (mode & 2) {
         const int64_t nid = P.n_knots * B.n;
         if (nid > 0) hipLaunchKernelGGL(k_small_identity, dim3((unsigned)((nid + 255) / 256)), dim3(256), 0, st, P, B, jac);
     }
-    if (P.n_int <= 0) return;
+    if (P.n_int <= 0) return hipGetLastError();
     SmallArgs a{};
     a.P = P; a.B = B; a.ty_fw = ty_fw; a.ty_ad = ty_ad; a.Gs = Gs; a.Z = dZ; a.mu = dmu;
     a.cons = cons; a.jac = jac; a.hess = hess; a.mode = mode;
     const int n = B.n, m = B.m;
-    const size_t bytes = small_lds_bytes(n, m, ty_fw.T, ty_ad.T);
+    size_t bytes = small_lds_bytes(n, m, ty_fw.T, ty_ad.T);
+    if (P.debug_bad_launch) bytes += 512 * 1024;  // more LDS than a CU has: the runtime must reject the launch
     // n <= 16: one wavefront per interval; 17..32: four (the n^3 products of the matrix exponential dominate there).
     // (A variant for 33..64 -- MFMA products on zero-padded matrices, generators left in global memory -- was correct
     // but slower than the general path at N = 1000: one 130 KB workgroup per CU and scalar sweeps; dropped.)
-    if (n <= 16) {
-        hipLaunchKernelGGL(k_small<64>, dim3((unsigned)P.n_int), dim3(64), bytes, st, a);
-    } else {
-        static size_t have = 0;  // dynamic LDS beyond 64 KB has to be opted into, per kernel
-        if (bytes > have) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small<256>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            if (e != hipSuccess) fprintf(stderr, "dto: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed: %s\n", bytes, hipGetErrorString(e));
-            else have = bytes;
-        }
-        hipLaunchKernelGGL(k_small<256>, dim3((unsigned)P.n_int), dim3(256), bytes, st, a);
-    }
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) fprintf(stderr, "dto: fused-interval kernel launch failed (n=%d, %zu B LDS): %s\n", n, bytes, hipGetErrorString(e));
+    if (n <= 16) hipLaunchKernelGGL(k_small<64>, dim3((unsigned)P.n_int), dim3(64), bytes, st, a);
+    else hipLaunchKernelGGL(k_small<256>, dim3((unsigned)P.n_int), dim3(256), bytes, st, a);
+    return hipGetLastError();
 }
 
 // LDS bytes the fused kernel needs for one interval (the engine falls back to the general path beyond the CU's 160 KB)

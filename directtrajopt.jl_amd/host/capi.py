@@ -8,7 +8,8 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 3
+DTO_ABI_VERSION = 4
+FLAG_GENERAL_PATH_ONLY = 1
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL = 1, 2, 3
 OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK, OBJECTIVE_EXTERNAL_GLOBAL = 1, 2, 3, 4, 5, 6, 7
 CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL, CONSTRAINT_EXTERNAL_GLOBAL = 1, 2, 3, 4
@@ -41,7 +42,7 @@ class ProblemDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("N", C.c_int64), ("z", C.c_int32),
                 ("gd", C.c_int32), ("dt_idx", C.c_int32), ("eval_hessian", C.c_int32),
                 ("n_integrators", C.c_int32), ("n_objectives", C.c_int32), ("n_constraints", C.c_int32),
-                ("reserved", C.c_int32), ("integrators", C.POINTER(IntegratorDesc)),
+                ("flags", C.c_int32), ("integrators", C.POINTER(IntegratorDesc)),
                 ("objectives", C.POINTER(ObjectiveDesc)), ("constraints", C.POINTER(ConstraintDesc)),
                 ("Z0", c_double_p), ("k_lo", C.c_int64), ("k_hi", C.c_int64)]
 

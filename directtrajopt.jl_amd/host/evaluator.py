@@ -25,6 +25,23 @@ def _ip(a):
     return a.ctypes.data_as(capi.c_int64_p)
 
 
+def _out(a, n, what):
+    """An output buffer the engine writes `n` doubles into: it must be a C-contiguous float64 ndarray of exactly that
+    size (the engine's device-to-host copy would otherwise run past it or land in the wrong bytes)."""
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"] or not a.flags["WRITEABLE"]:
+        raise ValueError(f"{what}: need a writeable C-contiguous float64 ndarray")
+    if a.size != n:
+        raise ValueError(f"{what}: length {a.size}, the engine writes {n} (shard-local slab lengths are in Evaluator.shard)")
+    return _dp(a)
+
+
+def _in(a, n, what):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.size != n:
+        raise ValueError(f"{what}: length {a.size}, expected {n}")
+    return a
+
+
 def _flatten_objective(obj):
     if obj is None or isinstance(obj, NullObjective):
         return []
@@ -47,7 +64,7 @@ class Evaluator:
     ``k_lo..k_hi`` (1-based, inclusive).  Inputs ``Z`` and ``mu`` are always the GLOBAL vectors;
     value outputs are the shard-local slabs described by ``shard`` (whole vectors when unsharded)."""
 
-    def __init__(self, prob, eval_hessian=True, device=0, k_lo=0, k_hi=0, verbose=False):
+    def __init__(self, prob, eval_hessian=True, device=0, k_lo=0, k_hi=0, verbose=False, general_path_only=False):
         self._lib = load_library()
         self._h = capi.H()
         traj = prob.trajectory
@@ -165,7 +182,8 @@ class Evaluator:
         Z0 = np.ascontiguousarray(traj.vec(), dtype=np.float64)
         desc = capi.ProblemDesc(capi.DTO_ABI_VERSION, device, traj.N, traj.dim, traj.global_dim,
                                 traj.components[traj.timestep][0], int(eval_hessian), len(prob.integrators),
-                                len(terms), len(nl), 0, integ, objs, cons, _dp(Z0), k_lo, k_hi)
+                                len(terms), len(nl), capi.FLAG_GENERAL_PATH_ONLY if general_path_only else 0, integ, objs, cons,
+                                _dp(Z0), k_lo, k_hi)
         if self._lib.dto_create(C.byref(desc), C.byref(self._h)) != 0:
             raise EngineError(self._lib.dto_last_error(None).decode())
         v = C.c_int64()
@@ -273,12 +291,12 @@ class Evaluator:
     def eval_objective_gradient(self, grad, Z):  # evaluator.jl:310
         Z = self._Z(Z)
         self._stage_external(Z, obj_need=1)
-        self._check(self._lib.dto_eval_gradient(self._h, _dp(Z), _dp(grad)))
+        self._check(self._lib.dto_eval_gradient(self._h, _dp(Z), _out(grad, self.shard.grad_len, "grad")))
 
     def eval_constraint(self, g, Z):  # evaluator.jl:323
         Z = self._Z(Z)
         self._stage_external(Z, con_need=0)
-        self._check(self._lib.dto_eval_constraint(self._h, _dp(Z), _dp(g)))
+        self._check(self._lib.dto_eval_constraint(self._h, _dp(Z), _out(g, self.shard.cons_len, "g")))
 
     def jacobian_structure(self, first=0, count=None):  # evaluator.jl:364 (1-based pairs)
         count = self.n_jacobian_entries - first if count is None else count
@@ -290,7 +308,7 @@ class Evaluator:
     def eval_constraint_jacobian(self, vals, Z):  # evaluator.jl:368
         Z = self._Z(Z)
         self._stage_external(Z, con_need=1)
-        self._check(self._lib.dto_eval_jacobian(self._h, _dp(Z), _dp(vals)))
+        self._check(self._lib.dto_eval_jacobian(self._h, _dp(Z), _out(vals, self.shard.jac_len, "vals")))
 
     def hessian_lagrangian_structure(self, first=0, count=None):  # evaluator.jl:385
         count = self.n_hessian_entries - first if count is None else count
@@ -301,21 +319,21 @@ class Evaluator:
 
     def eval_hessian_lagrangian(self, H, Z, sigma, mu):  # evaluator.jl:389
         Z = self._Z(Z)
-        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        mu = _in(mu, self.n_constraints, "mu")
         self._stage_external(Z, con_need=2, obj_need=2 if sigma != 0.0 else -1, mu=mu)
-        self._check(self._lib.dto_eval_hessian(self._h, _dp(Z), float(sigma), _dp(mu), _dp(H)))
+        self._check(self._lib.dto_eval_hessian(self._h, _dp(Z), float(sigma), _dp(mu), _out(H, self.shard.hess_len, "H")))
 
     def eval_constraint_jacobian_product(self, y, Z, w):  # evaluator.jl:406 (y = J w)
         Z = self._Z(Z)
-        w = np.ascontiguousarray(w, dtype=np.float64)
+        w = _in(w, self.n_variables, "w")
         self._stage_external(Z, con_need=1)
-        self._check(self._lib.dto_eval_jacobian_product(self._h, _dp(Z), _dp(w), _dp(y)))
+        self._check(self._lib.dto_eval_jacobian_product(self._h, _dp(Z), _dp(w), _out(y, self.n_constraints, "y")))
 
     def eval_constraint_jacobian_transpose_product(self, y, Z, w):  # evaluator.jl:432 (y = J' w)
         Z = self._Z(Z)
-        w = np.ascontiguousarray(w, dtype=np.float64)
+        w = _in(w, self.n_constraints, "w")
         self._stage_external(Z, con_need=1)
-        self._check(self._lib.dto_eval_jacobian_transpose_product(self._h, _dp(Z), _dp(w), _dp(y)))
+        self._check(self._lib.dto_eval_jacobian_transpose_product(self._h, _dp(Z), _dp(w), _out(y, self.n_variables, "y")))
 
     def constraint_bounds(self):  # get_nonlinear_constraints, src/solvers/solve.jl:30-65
         lo = np.empty(self.n_constraints)

@@ -11,7 +11,11 @@
  *   - Matrices are dense COLUMN-MAJOR (Julia's native layout).
  *   - The NLP variable vector is Z = [datavec; global_data], datavec knot-major
  *     (src/solvers/evaluator.jl:230, 474-482); component offsets are 0-based inside a knot.
- *   - Return value 0 = OK, non-zero = error; text via dto_last_error().
+ *   - Return value 0 = OK, non-zero = error; text via dto_last_error().  A kernel launch the HIP runtime rejects
+ *     (hipGetLastError after the call's launches) is such an error.  Errors that only show once the device has
+ *     run -- a generator sweep that exhausted its step budget -- are reported by the blocking entry points at once,
+ *     and by the `*_dev` entry points on the NEXT call through the ABI on that handle (any entry point, including
+ *     dto_last_stats, which synchronises): that call returns non-zero without doing its own work and clears the flag.
  *   - One in-flight call per handle (solvers call back serially).
  *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (passed as void*); inputs and outputs
  *     stay in HBM and the call returns with the last kernels still in flight on `stream`.  They may wait
@@ -31,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 3
+#define DTO_ABI_VERSION 4
 
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
@@ -124,6 +128,10 @@ typedef struct dto_constraint_desc {
     const double* hess0;    /* EXTERNAL_GLOBAL only: Hessian of sum(g) at Z0, n_comps x n_comps column-major */
 } dto_constraint_desc;
 
+/* dto_problem_desc.flags */
+#define DTO_FLAG_GENERAL_PATH_ONLY 1 /* bilinear integrators with <= 32 states also take the batched-GEMM path instead of
+                                        the fused one-workgroup-per-interval kernel (tests run both and compare) */
+
 typedef struct dto_problem_desc {
     int32_t abi_version;    /* DTO_ABI_VERSION */
     int32_t device;         /* HIP device ordinal */
@@ -136,7 +144,7 @@ typedef struct dto_problem_desc {
     int32_t n_integrators;
     int32_t n_objectives;
     int32_t n_constraints;
-    int32_t reserved;
+    int32_t flags;          /* DTO_FLAG_* bits, 0 by default */
     const dto_integrator_desc* integrators;
     const dto_objective_desc* objectives;
     const dto_constraint_desc* constraints;
@@ -238,6 +246,10 @@ int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const do
 /*   "expm_form" (default 0): evaluation form of the matrix-exponential polynomial in eval_constraint_jacobian.  0 picks per
  *   call by cost: two products for the degree-16 Taylor polynomial (backward-error radius 0.78) or three products for an
  *   order-26 approximant (radius 2.82, i.e. up to two squarings fewer); 2 / 3 force one form (tests, measurements). */
+/*   "chain_chunk" (default 0 = the engine's workspace budget): at most this many intervals per chunk of the propagator
+ *   chain (what a 16000-knot trajectory does by itself; tests use it to exercise the chunk loop on small problems).
+ *   "debug_bad_launch" (default 0): tests of the error convention -- 1 gives the next callbacks' kernels an invalid launch
+ *   configuration, which must come back as a non-zero return code with text. */
 int dto_set_option(dto_handle* h, const char* name, int64_t value);
 
 /* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */

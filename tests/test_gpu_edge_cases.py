@@ -146,61 +146,82 @@ def test_jacobian_vector_products():
         ev.close()
 
 
-def test_generic_path_on_small_states_in_subprocess():
-    """n <= 16 normally takes the fused small-state kernel; DTO_SMALL_N=0 forces the batched-GEMM path
+def test_generic_path_on_small_states():
+    """n <= 16 normally takes the fused small-state kernel; DTO_FLAG_GENERAL_PATH_ONLY forces the batched-GEMM path
     (padding to 64, generator sweeps) on the same problems so both stay parity-checked."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, os\n"
-        "root = os.environ['DTO_ROOT']\n"
-        "for p in (root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')): sys.path.insert(0, p)\n"
-        "import numpy as np, dto_amd, dto_oracle as O\n"
-        "from helpers import to_engine, rel_err, run_all\n"
-        "for p in (O.make_standard_problem(N=7), O.make_scaled_problem(5, 9, 3, seed=5, with_constraint=True), O.make_readme_problem()):\n"
-        "    ev_o = O.OracleEvaluator(p); ev = dto_amd.Evaluator(to_engine(p))\n"
-        "    mu = np.random.default_rng(1).standard_normal(ev_o.n_constraints)\n"
-        "    out = run_all(ev, p, p.Z0, mu, sigma=0.5)\n"
-        "    assert rel_err(out['cons'], ev_o.eval_constraint(p.Z0)) <= 1e-10\n"
-        "    assert rel_err(out['jac'], ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10\n"
-        "    assert rel_err(out['hess'], ev_o.eval_hessian_lagrangian(p.Z0, 0.5, mu)) <= 1e-8\n"
-        "    assert ev.last_stats()[1] >= 1  # the generator sweep of the general path ran (the fused kernel reports 0 terms)\n"
-        "    ev.close()\n"
-        "print('generic-ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DTO_SMALL_N="0", DTO_ROOT=root)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "generic-ok" in r.stdout, r.stdout + r.stderr
+    import dto_amd
+    for p in (O.make_standard_problem(N=7), O.make_scaled_problem(5, 9, 3, seed=5, with_constraint=True), O.make_readme_problem()):
+        ev_o = O.OracleEvaluator(p)
+        ev = dto_amd.Evaluator(to_engine(p), general_path_only=True)
+        mu = np.random.default_rng(1).standard_normal(ev_o.n_constraints)
+        out = run_all(ev, p, p.Z0, mu, sigma=0.5)
+        assert rel_err(out["cons"], ev_o.eval_constraint(p.Z0)) <= 1e-10
+        assert rel_err(out["jac"], ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10
+        assert rel_err(out["hess"], ev_o.eval_hessian_lagrangian(p.Z0, 0.5, mu)) <= 1e-8
+        assert ev.last_stats()[1] >= 1  # the generator sweep of the general path ran (the fused kernel reports 0 terms)
+        ev.close()
 
 
-def test_chunked_propagator_chain_in_subprocess():
-    """DTO_CHAIN_CHUNK=8 splits the 20 intervals of the chain into three chunks (what 16000 knots do with the default
+def test_chunked_propagator_chain():
+    """Option chain_chunk = 8 splits the 20 intervals of the chain into three chunks (what 16000 knots do with the default
     workspace budget): each chunk reads back its own squaring counts and picks its own polynomial form -- the time steps
     are chosen so that the chunks disagree (alpha ~ 1.5 in the first, ~ 4.5 in the others)."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, os\n"
-        "root = os.environ['DTO_ROOT']\n"
-        "for p in (root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')): sys.path.insert(0, p)\n"
-        "import numpy as np, dto_amd, dto_oracle as O\n"
-        "from helpers import to_engine, rel_err\n"
-        "p = O.make_scaled_problem(21, 40, 3, seed=9)\n"
-        "Z = p.Z0.copy(); dt = np.full(p.N, 0.28); dt[:8] = 0.09; Z[p.dt_idx::p.z] = dt\n"
-        "ref = O.OracleEvaluator(p).eval_constraint_jacobian(Z)\n"
-        "ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)\n"
-        "for form in (0, 2, 3):\n"
-        "    ev.set_option('expm_form', form)\n"
-        "    j = np.full(ev.shard.jac_len, np.nan); ev.eval_constraint_jacobian(j, Z)\n"
-        "    assert rel_err(j, ref) <= 1e-10, (form, rel_err(j, ref))\n"
-        "ev.close()\n"
-        "print('chunked-ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DTO_CHAIN_CHUNK="8", DTO_ROOT=root)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "chunked-ok" in r.stdout, r.stdout + r.stderr
+    import dto_amd
+    p = O.make_scaled_problem(21, 40, 3, seed=9)
+    Z = p.Z0.copy()
+    dt = np.full(p.N, 0.28)
+    dt[:8] = 0.09
+    Z[p.dt_idx::p.z] = dt
+    ref = O.OracleEvaluator(p).eval_constraint_jacobian(Z)
+    ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False)
+    ev.set_option("chain_chunk", 8)
+    for form in (0, 2, 3):
+        ev.set_option("expm_form", form)
+        j = np.full(ev.shard.jac_len, np.nan)
+        ev.eval_constraint_jacobian(j, Z)
+        assert rel_err(j, ref) <= 1e-10, (form, rel_err(j, ref))
+    ev.close()
+
+
+def test_rejected_kernel_launch_comes_back_as_an_error():
+    """include/dto_engine.h error convention: non-zero return + text.  Option debug_bad_launch gives the callbacks' kernels a
+    launch configuration the hardware does not have (block of 4096 threads on the general path, 512 KB of LDS more than a CU
+    owns on the fused small-state path); the call must fail through the ABI, and the handle must work again afterwards."""
+    import dto_amd
+    from dto_amd.host.evaluator import EngineError
+    for general in (False, True):
+        p = O.make_scaled_problem(5, 9, 2, seed=8, with_constraint=True)
+        ev_o = O.OracleEvaluator(p)
+        ev = dto_amd.Evaluator(to_engine(p), general_path_only=general)
+        j = np.full(ev.shard.jac_len, np.nan)
+        ev.set_option("debug_bad_launch", 1)
+        with pytest.raises(EngineError, match="launch|invalid"):
+            ev.eval_constraint_jacobian(j, p.Z0)
+        g = np.full(ev.shard.cons_len, np.nan)
+        with pytest.raises(EngineError):
+            ev.eval_constraint(g, p.Z0)
+        ev.set_option("debug_bad_launch", 0)
+        ev.eval_constraint_jacobian(j, p.Z0)
+        assert rel_err(j, ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10
+        ev.close()
+
+
+def test_output_buffers_are_checked_on_the_host():
+    """A float32, strided or short output array must be refused before the engine copies into it."""
+    import dto_amd
+    p = O.make_scaled_problem(5, 9, 2, seed=8, with_constraint=True)
+    ev = dto_amd.Evaluator(to_engine(p), k_lo=2, k_hi=4)
+    n = ev.shard.jac_len
+    assert n < ev.n_jacobian_entries
+    for bad in (np.empty(ev.n_jacobian_entries), np.empty(n, dtype=np.float32), np.empty(2 * n)[::2], np.empty(n - 1)):
+        with pytest.raises(ValueError):
+            ev.eval_constraint_jacobian(bad, p.Z0)
+    with pytest.raises(ValueError):
+        ev.eval_hessian_lagrangian(np.empty(ev.shard.hess_len), p.Z0, 1.0, np.ones(ev.n_constraints - 1))
+    ok = np.empty(n)
+    ev.eval_constraint_jacobian(ok, p.Z0)
+    assert np.isfinite(ok).all()
+    ev.close()
 
 
 def test_large_norm_on_the_general_path_uses_substeps_and_many_squarings():
