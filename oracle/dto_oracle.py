@@ -390,11 +390,13 @@ def _second_frechet_action(A, E1, E2, x):
     return (top_right(E1, E2) + top_right(E2, E1)) @ x
 
 
-def bilinear_block_hessian(integ, prob, zk, mu):
+def bilinear_block_hessian(integ, prob, zk, mu, skip_uu=False):
     """Dense z x z Hessian of mu' f wrt z_k for the bilinear defect (x_{k+1} rows/cols are 0).
 
     Exact second derivative of bilinear_integrator.jl:81 (reference: ForwardDiff.hessian,
-    :135-161)."""
+    :135-161).  skip_uu leaves the (u_i, u_j) block at zero: its second-order Frechet terms need the exponential of
+    a 3n x 3n matrix, which at n = 1024 takes minutes per pair (the large-state tests check that block against central
+    differences of the Jacobian instead, the reference's own method, evaluator.jl:779-790)."""
     n, m, z = integ.x_dim, integ.u_dim, prob.z
     dt = zk[prob.dt_idx]
     x = zk[integ.x_off:integ.x_off + n]
@@ -415,7 +417,7 @@ def bilinear_block_hessian(integ, prob, zk, mu):
         val = -(mu @ (integ.G[1 + j] @ Ex + Gu @ (Ls[j] @ x)))
         H[uj, prob.dt_idx] += val
         H[prob.dt_idx, uj] += val
-        for i in range(j + 1):
+        for i in range(0 if skip_uu else j + 1):
             ui = integ.u_off + i
             val = -(mu @ _second_frechet_action(A, dt * integ.G[1 + i], dt * integ.G[1 + j], x))
             H[ui, uj] += val
@@ -428,7 +430,7 @@ def bilinear_block_hessian(integ, prob, zk, mu):
     return H
 
 
-def integrator_hessian(integ, prob, Z, mu):
+def integrator_hessian(integ, prob, Z, mu, skip_uu=False):
     """eval_hessian_of_lagrangian -- bilinear_integrator.jl:135-161, derivative_integrator.jl:90-116."""
     d, z = integ.x_dim, prob.z
     H = sp.lil_matrix((prob.n_vars, prob.n_vars))
@@ -440,7 +442,7 @@ def integrator_hessian(integ, prob, Z, mu):
             zz = np.concatenate([zk, _knot(Z, prob, k + 1)])
             blk = np.asarray(integ.hess(zz, k, muk), dtype=np.float64).reshape(2 * z, 2 * z)
         elif integ.kind == "bilinear":
-            blk[:z, :z] = bilinear_block_hessian(integ, prob, zk, muk)
+            blk[:z, :z] = bilinear_block_hessian(integ, prob, zk, muk, skip_uu)
         else:
             for i in range(d):
                 blk[integ.xdot_off + i, prob.dt_idx] += -muk[i]
@@ -839,8 +841,9 @@ class OracleEvaluator:
                     out[idx] = vv
         return out
 
-    def eval_hessian_lagrangian(self, Z, sigma, mu):
-        """_fill_hessian_values! -- evaluator.jl:560-647 (accumulation, upper triangle only)."""
+    def eval_hessian_lagrangian(self, Z, sigma, mu, skip_uu=False):
+        """_fill_hessian_values! -- evaluator.jl:560-647 (accumulation, upper triangle only).
+        skip_uu: see bilinear_block_hessian (large-state tests only)."""
         out = np.zeros(len(self.hess_rows))
 
         def scatter(M, scale=1.0):
@@ -855,7 +858,7 @@ class OracleEvaluator:
 
         for i, integ in enumerate(self.prob.integrators):
             o = self.integrator_offsets[i]
-            scatter(integrator_hessian(integ, self.prob, Z, mu[o:o + integ.x_dim * self.prob.K]))
+            scatter(integrator_hessian(integ, self.prob, Z, mu[o:o + integ.x_dim * self.prob.K], skip_uu))
         for i, con in enumerate(self.prob.constraints):
             o = self.constraint_offsets[i]
             scatter(constraint_hessian(con, self.prob, Z, mu[o:o + con.g_dim * len(con.times1)]))
@@ -919,6 +922,30 @@ def make_scaled_problem(N, n, m=4, seed=42, with_constraint=False, skew=False, e
     if with_constraint:
         prob.constraints = [KnotConstraint("norm", list(range(n, n + m)), 1.0,
                                            list(range(2, N)), equality=False)]
+    return prob
+
+
+def make_l1_slack_problem(N, n, m=4, seed=42):
+    """BASELINE configs[4] / SURVEY section 8d "C5" on the hot path: components x[n], u[m], du[m], s_du[m], dt
+    (z = n + 3m + 1); [BilinearIntegrator(G,:x,:u), DerivativeIntegrator(:u,:du)]; the nonlinear inequality
+    NonlinearKnotPointConstraint(u -> [norm(u) - 1], times = 2:N-1, <= 0) of test/test_snippets.jl:39-45; objective
+    QuadraticRegularizer(:u, 1.0) + LinearRegularizer(:s_du, 1e-2) -- the penalty on the slack of an L1SlackConstraint
+    (src/constraints/linear/l1_slack_constraint.jl:28), whose own rows |du| <= s_du are linear and go to MOI directly,
+    not through the evaluator.  Same Philox stream and fill order as make_scaled_problem, then s_du = |du| + 0.1."""
+    z = n + 3 * m + 1
+    r = philox_normal(seed, (m + 1) * n * n + N * (n + 2 * m))
+    G = r[:(m + 1) * n * n].reshape(m + 1, n, n).transpose(0, 2, 1).copy()
+    rest = r[(m + 1) * n * n:]
+    x = rest[:n * N].reshape(N, n).T
+    u = 0.1 * rest[n * N:n * N + m * N].reshape(N, m).T
+    du = rest[n * N + m * N:].reshape(N, m).T
+    data = np.vstack([x, u, du, np.abs(du) + 0.1, np.full((1, N), 0.1)])
+    prob = Problem(
+        N=N, z=z, dt_idx=n + 3 * m,
+        integrators=[BilinearIntegrator(0, n, n, m, G), DerivativeIntegrator(n, m, n + m)],
+        objectives=[QuadraticRegularizer(n, m, np.ones(m)), LinearRegularizer(n + 2 * m, m, np.full(m, 1e-2))],
+        Z0=data.T.reshape(-1).copy())
+    prob.constraints = [KnotConstraint("norm", list(range(n, n + m)), 1.0, list(range(2, N)), equality=False)]
     return prob
 
 

@@ -188,7 +188,7 @@ def test_rejected_kernel_launch_comes_back_as_an_error():
     launch configuration the hardware does not have (block of 4096 threads on the general path, 512 KB of LDS more than a CU
     owns on the fused small-state path); the call must fail through the ABI, and the handle must work again afterwards."""
     import dto_amd
-    from dto_amd.host.evaluator import EngineError
+    EngineError = dto_amd.EngineError
     for general in (False, True):
         p = O.make_scaled_problem(5, 9, 2, seed=8, with_constraint=True)
         ev_o = O.OracleEvaluator(p)
