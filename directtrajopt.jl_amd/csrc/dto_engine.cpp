@@ -186,6 +186,8 @@ struct dto_handle {
     std::vector<hipEvent_t> ev_pool;  // recycled timing events (creating them inside the timed region costs host time)
     int last_smax = 0, last_terms = 0;
     int expm_form = 0;  // option "expm_form": 0 = by cost, 2 / 3 = forced
+    int sweep_form = 0;   // option "sweep_form": 0 = fused persistent sweep where it applies, 1 = step-per-launch form only
+    int n_cu = 256;
     int chain_chunk = 0;  // option "chain_chunk": upper bound on the intervals per chain chunk (0: workspace capacity)
     // deferred errors of the `*_dev` entry points (dto_engine.h, error convention): the sweep statistics of the last
     // asynchronous call are copied to pinned memory behind its kernels and looked at by the next call through the ABI
@@ -366,6 +368,7 @@ void alloc_sweep(dto_handle* h, BilHost& b, SweepBuf& w, int T, bool with_W) {
     w.npad = npad;
     w.T_alloc = T;
     w.TN = (npad % 128 == 0) ? 128 : 64;
+    w.nblk = w.TN;
     int64_t nint = std::max<int64_t>(h->P.n_int, 1);
     w.Kpad = (int)(((nint + w.TN - 1) / w.TN) * w.TN);
     const size_t typesz = (size_t)w.Kpad * npad;
@@ -462,12 +465,38 @@ SweepPlan plan_sweep(double beta) {
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
               int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false,
-              bool skip_init = false) {
+              bool skip_init = false, bool want_steps = false) {
     const double flops_step = [&] {
         double segs = 0;
         for (int t = w.frozen ? w.first_type : 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
         return 2.0 * b.k.npad * (double)b.k.npad * w.Kpad * segs;
     }();
+    // The termination test cannot fire early in the series: it is first run at step tc = d_ub/2 - 1 (d_ub comes from an
+    // upper bound on the terms needed at this very Z, so tc is a function of Z alone and results stay reproducible; a
+    // column block that would pass earlier merely adds a few terms below 1e-16 of its sum).
+    static const int tc_env = tune_int("DTO_SWEEP_TC", -1);
+    int tc = tc_env >= 0 ? tc_env : plan.d_ub / 2 - 1;
+    if (tc < 2) tc = 0;
+    // Fused form (dto_sweep_fused.hip): the whole series in one persistent launch, a workgroup per few intervals.  The
+    // step-per-launch form below remains for single-type sweeps (split-K over the generators serves those better), for
+    // sweeps over frozen p terms and for the products' extra start vector.
+    FusedSweepPlan fp;
+    if (h->sweep_form != 1 && !w.frozen && !skip_init && ty.T >= 2 && (!store || (w.Zt && plan.d_ub + 1 <= w.dcap)) &&
+        sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp)) {
+        w.nblk = fp.ipw;
+        HIP_CHECK(hipMemsetAsync(w.stats, 0, 4 * sizeof(int32_t), st));
+        {
+            // flops of the step budget (an upper bound: workgroups leave when their columns have converged)
+            ProfScope ps(h, st, CAT_SWEEP, flops_step * plan.d_ub * plan.q);
+            HIP_CHECK(launch_sweep_fused(st, h->P, b.k, w, ty, fp, dZ, dmu, src_kind, transposed, plan.q, plan.d_ub, tc, store, 1.1e-16));
+        }
+        if (!want_steps) return plan.d_ub;
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 6);
+        HIP_CHECK(hipMemcpyAsync(hs, w.stats, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return std::max(1, std::min(hs[1] - 1, plan.d_ub));
+    }
+    w.nblk = w.TN;
     const size_t tstride = (size_t)ty.T * w.Kpad * w.npad;
     SweepBuf ws = w;
     if (store) ws.Z[0] = w.Zt;
@@ -484,13 +513,8 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
         launched = 0;
         bool pending = false;
         int slot = 0;
-        // The termination test cannot fire early in the series: it is first run at step tc = d_ub/2 - 1 (d_ub comes from
-        // an upper bound on the terms needed at this very Z, so tc is a function of Z alone and results stay reproducible;
-        // a column block that would pass earlier merely adds a few terms below 1e-16 of its sum).  Each test left out is one
-        // kernel and one dependent-launch gap less (~12 us).  The term-norm slots the tests recycle are cleared once instead.
-        static const int tc_env = tune_int("DTO_SWEEP_TC", -1);
-        int tc = tc_env >= 0 ? tc_env : plan.d_ub / 2 - 1;
-        if (tc < 2) tc = 0;
+        // (each termination test left out before tc is one kernel and one dependent-launch gap less, ~12 us; the term-norm
+        // slots the tests recycle are cleared once instead)
         for (int t = 0; t < plan.d_ub; ++t) {
             if (tc > 0 && t == tc - 1)
                 HIP_CHECK(hipMemsetAsync(w.termnorm, 0, sizeof(unsigned long long) * (size_t)3 * w.T_alloc * w.Kpad, st));
@@ -1019,7 +1043,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
             }
             SweepTypes ty1 = make_types(m, false);
-            const int steps_a = run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair);
+            const int steps_a = run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair, false, /*want_steps=*/pair);
             launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
             launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
             if (pair) {
@@ -1029,8 +1053,8 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 const int64_t typesz = (int64_t)b.fw.Kpad * b.k.npad;
                 const int64_t cols = (int64_t)na * b.fw.Kpad;  // one type of every stored term
                 SweepBuf plain = b.fw;
-                if (Tf == 1) plain.nterms = b.fw.nterms_p;  // (a frozen Jacobian sweep in between re-used fw.nterms)
-                launch_pair_combine(st, plain, Tf, 1, na, nf, b.ad.nterms, b.d_Btab, b.Upair);
+                if (Tf == 1) { plain.nterms = b.fw.nterms_p; plain.nblk = b.fw.TN; }  // (a frozen Jacobian sweep in between re-used fw.nterms)
+                launch_pair_combine(st, plain, Tf, 1, na, nf, b.ad.nterms, b.ad.nblk, b.d_Btab, b.Upair);
                 {
                     ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m);
                     launch_apply_generators_cols(st, b.k, b.fw, 0, b.Upair, b.EP, 1, m, cols, b.fw.Kpad, (int64_t)Tf * typesz);
@@ -1181,6 +1205,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+            HIP_CHECK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+            HIP_CHECK(sweep_fused_prepare());
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;
@@ -1207,7 +1233,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 b.k.n = s.x_dim; b.k.m = s.u_dim; b.k.npad = pad64(s.x_dim);
                 b.k.x_off = s.x_off; b.k.u_off = s.u_off; b.k.pre = pre; b.k.row_off = row;
                 const int n = s.x_dim, np = b.k.npad, m1 = s.u_dim + 1;
-                std::vector<double> G((size_t)m1 * np * np, 0.0), GT((size_t)m1 * np * np, 0.0);
+                // (+ 16 zero columns: the fused sweep streams the generators a few k-steps ahead, past the last one)
+                std::vector<double> G((size_t)m1 * np * np + 16 * (size_t)np, 0.0), GT((size_t)m1 * np * np + 16 * (size_t)np, 0.0);
                 b.g1.assign(m1, 0.0);
                 for (int j = 0; j < m1; ++j)
                     for (int c = 0; c < n; ++c) {
@@ -1602,10 +1629,11 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                     for (SweepBuf* w : {&b.fw, &b.ad}) {
                         w->Zt = own(h, dalloc<double>(store));
                         w->dcap = dcap;
-                        w->nterms = own(h, dalloc<int32_t>(w->Kpad / w->TN));
-                        HIP_CHECK(hipMemset(w->nterms, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
-                        w->nterms_p = own(h, dalloc<int32_t>(w->Kpad / w->TN));
-                        HIP_CHECK(hipMemset(w->nterms_p, 0, sizeof(int32_t) * (w->Kpad / w->TN)));
+                        // one entry per convergence block; the fused sweep's blocks are as small as one interval
+                        w->nterms = own(h, dalloc<int32_t>(w->Kpad));
+                        HIP_CHECK(hipMemset(w->nterms, 0, sizeof(int32_t) * w->Kpad));
+                        w->nterms_p = own(h, dalloc<int32_t>(w->Kpad));
+                        HIP_CHECK(hipMemset(w->nterms_p, 0, sizeof(int32_t) * w->Kpad));
                     }
                     b.EP = own(h, dalloc<double>((size_t)m * dcap * b.fw.Kpad * b.k.npad));  // G_j' U_a
                     b.Upair = own(h, dalloc<double>(store));
@@ -1934,6 +1962,12 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
     if (!h || !name) return 1;
     if (std::string(name) == "reuse_forward_sweep") {
         h->reuse = value != 0;
+        drop_caches(h);
+        return 0;
+    }
+    if (std::string(name) == "sweep_form") {
+        if (value != 0 && value != 1) return fail(h, "dto_set_option: sweep_form takes 0 (fused where it applies) or 1 (step per launch)");
+        h->sweep_form = (int)value;
         drop_caches(h);
         return 0;
     }

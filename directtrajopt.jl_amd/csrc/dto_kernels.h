@@ -208,6 +208,8 @@ struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear i
     const double* frozen;    // stored p terms (nullptr: the sweep computes its own p column)
     int32_t frozen_total;    // terms 0 .. frozen_total-1 were stored
     int32_t first_type;      // first column type the sweep computes (1 with frozen p terms, else 0)
+    int32_t nblk;            // intervals per entry of nterms / nterms_p (the last sweep's convergence blocks: TN for the
+                             // step-per-launch form, the workgroup's interval count for the fused form)
 };
 
 // src_kind: 0 = state x_k of the integrator (forward sweep), 1 = multipliers mu_k (adjoint sweep)
@@ -224,6 +226,20 @@ void launch_jv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const Swe
 void launch_jtv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad, const double* w, double* y);
 void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const double* dZ, const double* w, double* y, int transpose);
 
+// ---- the whole sweep in one persistent launch (dto_sweep_fused.hip): a workgroup owns `ipw` intervals, all rows, all types
+struct FusedSweepPlan {
+    int MT, NT, ipw, nslot, nblocks;
+    size_t lds_bytes;
+};
+hipError_t sweep_fused_prepare();  // per-device opt-in to the kernels' dynamic LDS (dto_create)
+bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, FusedSweepPlan& out);
+// Runs q rounds of at most d_ub Taylor steps (termination test from step tc on, per workgroup), terms into w.Zt (store) or
+// ping-pong w.Z[0/1], sums into w.S, scale factors into w.scale*, valid term counts into w.nterms[workgroup],
+// w.stats[0] += workgroups that did not converge, w.stats[1] = max terms used (the caller zeroes w.stats).
+hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
+                              const FusedSweepPlan& pl, const double* dZ, const double* dmu, int src_kind, int transposed,
+                              int q, int d_ub, int tc, bool store, double tol);
+
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
                        int t, int in_buf, int split_store = 0);
 void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);
@@ -238,7 +254,7 @@ void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf&
                                   int64_t seg_stride = 0);
 // U[a][type][k][:] = sum_b Btab[a][b] * terms[b][type][k][:]   (Beta-function weights of the pairing formula)
 void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int n_types, int nf_used, int na_used,
-                         const int32_t* nterms_f, const double* Btab, double* U);
+                         const int32_t* nterms_f, int nblk_f, const double* Btab, double* U);
 // (u_i,u_j) block of the bilinear Hessian from the pairing formula (see k_hess_pair)
 void launch_hess_pair(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, int nf_used, const double* EP,
                       double* H);

@@ -1187,14 +1187,14 @@ void launch_apply_generators_cols(hipStream_t st, const KBil& B, const SweepBuf&
 
 // U[a][type][k][r] = sum_{b < na} Btab[a][b] * terms[b][type][k][r]  for a < nf (valid term counts per column block)
 __global__ void __launch_bounds__(256) k_pair_combine(SweepBuf ad, int T, int nf_used, int na_used,
-                                                     const int32_t* __restrict__ nterms_f, const double* __restrict__ Btab,
-                                                     double* __restrict__ U) {
+                                                     const int32_t* __restrict__ nterms_f, int nblk_f,
+                                                     const double* __restrict__ Btab, double* __restrict__ U) {
     const int64_t typesz = (int64_t)ad.Kpad * ad.npad;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (k, r)
     if (e >= typesz) return;
     const int type = blockIdx.y;
-    const int ct = (int)((e / ad.npad) / ad.TN);
-    int nf = nterms_f[ct], na = ad.nterms[ct];
+    const int col = (int)(e / ad.npad);
+    int nf = nterms_f[col / nblk_f], na = ad.nterms[col / ad.nblk];
     if (nf <= 0 || nf > nf_used) nf = nf_used;
     if (na <= 0 || na > na_used) na = na_used;
     const int64_t tstride = (int64_t)T * typesz;
@@ -1213,10 +1213,10 @@ __global__ void __launch_bounds__(256) k_pair_combine(SweepBuf ad, int T, int nf
     }
 }
 void launch_pair_combine(hipStream_t st, const SweepBuf& ad, int T, int n_types, int nf_used, int na_used,
-                         const int32_t* nterms_f, const double* Btab, double* U) {
+                         const int32_t* nterms_f, int nblk_f, const double* Btab, double* U) {
     const int64_t typesz = (int64_t)ad.Kpad * ad.npad;
     hipLaunchKernelGGL(k_pair_combine, dim3((unsigned)((typesz + 255) / 256), n_types), dim3(256), 0, st, ad, T, nf_used, na_used,
-                       nterms_f, Btab, U);
+                       nterms_f, nblk_f, Btab, U);
 }
 
 // (u_i, u_j) block of mu_k' f by the pairing formula.  With p_a, d^i_a the Taylor terms of ONE sweep with tangents
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
     const int64_t typesz = (int64_t)fw.Kpad * npad;
     const int64_t tstride = (int64_t)T * typesz;          // one stored Taylor term of all forward types
     const int64_t gstride = (int64_t)nf_used * typesz;    // one generator in EP (nf_used terms)
-    int nf = fw.nterms[kl / fw.TN];
+    int nf = fw.nterms[kl / fw.nblk];
     if (nf <= 0 || nf > nf_used) nf = nf_used;
     double acc[M][M];
     for (int i = 0; i < m; ++i)

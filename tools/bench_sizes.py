@@ -1,38 +1,46 @@
-import sys, time, json
-sys.path.insert(0,'/root/repo')
+"""Callback times at other shapes than the headline's, with the fused sweep and the step-per-launch sweep (option sweep_form)
+side by side.  usage: python tools/bench_sizes.py [--big]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, dto_amd
-def run(n, m, N, cb="jacobian", steps=3):
-    prob = dto_amd.host.synthetic.make_scaled_problem(N, n, m, seed=42)
-    ev = dto_amd.Evaluator(prob, eval_hessian=(cb=="hessian"))
-    dev = torch.device("cuda",0)
+
+
+def run(n, m, N, cb="jacobian", steps=5, make=None):
+    prob = (make or dto_amd.host.synthetic.make_scaled_problem)(N, n, m, seed=42)
+    ev = dto_amd.Evaluator(prob, eval_hessian=(cb == "hessian"))
+    dev = torch.device("cuda", 0)
     Z = torch.from_numpy(prob.trajectory.vec()).to(dev)
     st = torch.cuda.current_stream(dev).cuda_stream
-    if cb=="jacobian":
+    if cb == "jacobian":
         out = torch.empty(ev.shard.jac_len, dtype=torch.float64, device=dev); f = lambda: ev.eval_jacobian_dev(Z.data_ptr(), out.data_ptr(), st)
-    elif cb=="hessian":
+    elif cb == "hessian":
         out = torch.empty(ev.shard.hess_len, dtype=torch.float64, device=dev); mu = torch.ones(ev.n_constraints, dtype=torch.float64, device=dev)
         f = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), out.data_ptr(), st)
     else:
         out = torch.empty(ev.shard.cons_len, dtype=torch.float64, device=dev); f = lambda: ev.eval_constraint_dev(Z.data_ptr(), out.data_ptr(), st)
-    f(); torch.cuda.synchronize()
-    t0=time.perf_counter()
-    for _ in range(steps): f()
-    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/steps
-    print(f"n={n} m={m} N={N} {cb}: {dt*1e3:.3f} ms  {N/dt:.0f} knot-points/s finite={bool(torch.isfinite(out).all())} stats={ev.last_stats()}", flush=True)
+    res = []
+    for form in (0, 1):
+        ev.set_option("sweep_form", form)
+        f(); f(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps): f()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        res.append(dt * 1e3)
+    print(f"n={n} m={m} N={N} {cb}: fused {res[0]:.3f} ms, step-per-launch {res[1]:.3f} ms  ({N / (res[0] * 1e-3):.0f} knot-points/s) "
+          f"finite={bool(torch.isfinite(out).all())} stats={ev.last_stats()}", flush=True)
     ev.close()
-for cb in ("constraint","jacobian","hessian"):
+
+
+for cb in ("constraint", "jacobian", "hessian"):
     run(64, 4, 1000, cb)
+for n, N in ((128, 1000), (256, 200), (256, 2000), (192, 500), (512, 500)):
+    for cb in ("jacobian", "hessian"):
+        run(n, 4, N, cb, steps=3)
 if "--big" in sys.argv:
-    for cb in ("constraint","jacobian","hessian"):
-        run(1024, 4, 500, cb, steps=2)  # configs[4] per-GPU share: N=4000 over 8 GPUs
-run(4, 2, 51, "jacobian"); run(4, 2, 51, "hessian")
-for cb in ("constraint","jacobian","hessian"):
-    run(32, 4, 100, cb, steps=5)
-for cb in ("constraint","jacobian","hessian"):
-    run(17, 3, 1000, cb, steps=5)
-if "--big" in sys.argv:
+    for cb in ("constraint", "jacobian", "hessian"):
+        run(1024, 4, 500, cb, steps=2, make=dto_amd.host.synthetic.make_l1_slack_problem)  # configs[4] per-GPU share: N=4000 over 8 GPUs
     for cb in ("jacobian", "hessian"):
         run(256, 4, 16000, cb, steps=2)  # configs[3] unsharded
-for n in (128, 512):
-    for cb in ("jacobian", "hessian"):
-        run(n, 4, 1000 if n == 128 else 500, cb)
+run(4, 2, 51, "jacobian"); run(4, 2, 51, "hessian")
+for cb in ("constraint", "jacobian", "hessian"):
+    run(32, 4, 100, cb)
