@@ -32,33 +32,77 @@ def baseline_metric():
         return "knot-points/sec for eval_constraint_jacobian, 256-state\u00d72000-knot bilinear"
 
 
-def cpu_baseline(n, m, N, budget_s=20.0):
-    """The oracle ("port") timed on the host cores on a bounded sample of the same workload: W
-    single-threaded worker processes (oracle/cpu_baseline_worker.py; W = the CPUs this process may
-    use, at most 16 = the box's share for one GPU) each evaluate the bilinear Jacobian blocks (scipy
-    expm + expm_frechet, oracle/dto_oracle.py) of every W-th interval of the same synthetic problem
-    until `budget_s` seconds are spent.  Knots are independent, so this is the CPU's parallel rate."""
+def _run_workers(cmds, env=None, timeout=600):
     import subprocess
+    procs = [subprocess.Popen(c, stdout=subprocess.PIPE, env=env, text=True) for c in cmds]
+    knots, dt = 0, 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=timeout)
+        if p.returncode != 0:
+            raise RuntimeError(f"cpu baseline worker exited with {p.returncode}")
+        f = out.split()
+        knots += int(f[0])
+        dt = max(dt, float(f[1]))
+    return knots, dt
+
+
+def build_ref_costmodel():
+    """gcc build of the reference-cost-model restatement (oracle/dto_ref_costmodel.c) ON THIS HOST (-march=native must
+    match the cores it is timed on, so a binary built elsewhere is not reused); returns the binary's path."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "dto_ref_costmodel.c")
+    exe = os.path.join(tempfile.mkdtemp(prefix="dto_ref_"), "dto_ref_costmodel")
+    subprocess.run(["gcc", "-O3", "-march=native", "-o", exe, src, "-lm"], check=True)
+    return exe
+
+
+def cpu_baseline(prob, n, m, N, budget_s=20.0):
+    """The reference's CPU path timed beside the GPU on the box's host cores, on a bounded sample of the same workload.
+
+    The reference is Julia and cannot run here, so the baseline is the C restatement of its ALGORITHM
+    (oracle/dto_ref_costmodel.c: serial walk over the intervals, ForwardDiff-style forward mode over the 2z inputs in
+    chunks of 12 through the truncated-Taylor `expv`, bilinear_integrator.jl:81,111-131): W single-threaded processes (W =
+    the CPUs this process may use = the box's share for one GPU) each take every W-th interval of the same synthetic
+    problem for `budget_s`/2 seconds; the same on ONE core; and, for context, the repository's own oracle (scipy
+    expm + expm_frechet per knot, a different and much cheaper algorithm) on W cores.  Knots are independent, so the
+    W-process figure is the CPU's parallel rate."""
+    import tempfile
+    import numpy as np
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    W = max(1, min(16, avail, N - 1))
-    worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, worker, ROOT, str(n), str(m), str(N), str(w), str(W), str(budget_s)],
-                              stdout=subprocess.PIPE, env=env, text=True) for w in range(W)]
-    knots, dt = 0, 0.0
-    for p in procs:
-        out, _ = p.communicate(timeout=budget_s * 6 + 300)
-        if p.returncode != 0:
-            raise RuntimeError(f"cpu baseline worker exited with {p.returncode}")
-        k, t = out.split()
-        knots += int(k)
-        dt = max(dt, float(t))
-    return {"value": knots / dt, "unit": "knot-points/s", "cores": W, "kind": "port",
-            "sample": f"oracle (scipy expm + {m} expm_frechet per knot), {W} single-threaded processes over "
-                      f"{knots} of the {N - 1} intervals of the same problem, {dt:.1f} s"}
+    W = max(1, min(avail, N - 1))
+    exe = build_ref_costmodel()
+    G = prob.integrators[0].G
+    z = prob.trajectory.dim
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.array([n, m, N, z], dtype=np.int64).tofile(f)
+        np.ascontiguousarray(np.transpose(G, (0, 2, 1))).tofile(f)  # column-major per generator
+        prob.trajectory.vec()[:N * z].tofile(f)
+        path = f.name
+    try:
+        k_all, t_all = _run_workers([[exe, "bench", path, str(w), str(W), str(budget_s / 2)] for w in range(W)])
+        k_one, t_one = _run_workers([[exe, "bench", path, "0", "1", str(budget_s / 4)]])
+    finally:
+        os.unlink(path)
+    out = {"value": k_all / t_all, "unit": "knot-points/s", "cores": W, "kind": "port",
+           "sample": f"reference-algorithm restatement in C (forward-mode duals in chunks of 12 through truncated-Taylor expv, "
+                     f"{-(-2 * z // 12)} chunks per knot): {W} single-threaded processes over {k_all} of the {N - 1} intervals of "
+                     f"the same problem in {t_all:.1f} s",
+           "one_core": {"value": k_one / t_one, "knots": k_one, "seconds": t_one}}
+    try:
+        worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.py")
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        Wo = min(W, 16)
+        k_o, t_o = _run_workers([[sys.executable, worker, ROOT, str(n), str(m), str(N), str(w), str(Wo), str(budget_s / 4)]
+                                 for w in range(Wo)], env=env)
+        out["scipy_oracle"] = {"value": k_o / t_o, "cores": Wo, "knots": k_o, "seconds": t_o,
+                               "note": "oracle/dto_oracle.py (scipy expm + expm_frechet): not the reference's algorithm"}
+    except Exception as e:
+        out["scipy_oracle"] = {"value": None, "note": f"failed: {e!r}"}
+    return out
 
 
 def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
@@ -247,7 +291,7 @@ def main():
             line["other_callbacks"] = other_callbacks(dto_amd, torch, prob, ev, dev, Z, stream, N_total)
         if world == 1 and not args.no_cpu_baseline and args.callback == "jacobian":
             try:
-                line["cpu_baseline"] = cpu_baseline(n, m, Nk, args.cpu_budget)
+                line["cpu_baseline"] = cpu_baseline(prob, n, m, Nk, args.cpu_budget)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "knot-points/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e!r}"}
