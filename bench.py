@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--gather", action="store_true",
+                    help="configs[3] data path: after the compute-only timing, time K more steps in which every rank's slab is "
+                         "written into the full value vector and all-gathered in place (RCCL over xGMI); reported next to `value`")
     args = ap.parse_args()
 
     import numpy as np
@@ -232,6 +235,47 @@ def main():
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
 
+    gather = None
+    if args.gather and dist is not None and args.callback in ("jacobian", "hessian"):
+        # every rank holds the WHOLE value vector; its engine writes the rank's slab straight into its slice, the other
+        # slices arrive by the in-place all-gather (dto_amd.distributed.gather_slabs_inplace): no padded copy, no cat
+        lo, ln = (sh.jac_lo, sh.jac_len) if args.callback == "jacobian" else (sh.hess_lo, sh.hess_len)
+        total = ev.n_jacobian_entries if args.callback == "jacobian" else ev.n_hessian_entries
+        gdev = dev if args.backend == "nccl" else dev
+        del out
+        full = torch.empty(total, dtype=torch.float64, device=gdev)
+        layout = dto_amd.distributed.slab_layout(lo, ln)
+        mine = full[lo:lo + ln]
+        if args.callback == "jacobian":
+            gstep = lambda: ev.eval_jacobian_dev(Z.data_ptr(), mine.data_ptr(), stream)
+        else:
+            gstep = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), mine.data_ptr(), stream)
+        for _ in range(max(1, args.warmup)):
+            gstep()
+            dto_amd.distributed.gather_slabs_inplace(full, layout)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gstep()
+            dto_amd.distributed.gather_slabs_inplace(full, layout)
+        fence()
+        t_both = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dto_amd.distributed.gather_slabs_inplace(full, layout)
+        fence()
+        t_gather = time.perf_counter() - t0
+        tt = torch.tensor([t_both, t_gather], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_both, t_gather = (float(x) for x in tt.tolist())
+        chk = bool(torch.isfinite(full[::max(1, total // 4096)]).all().item())
+        gather = {"n_ranks": dist.get_world_size(), "backend": args.backend, "bytes_per_rank_vector": 8.0 * total,
+                  "ms_per_step_compute_and_gather": t_both / args.steps * 1e3, "gather_ms": t_gather / args.steps * 1e3,
+                  "gather_gbs_per_rank_received": 8.0 * (total - ln) / (t_gather / args.steps) / 1e9,
+                  "knot_points_per_s_with_gather": N_total * args.steps / t_both, "sampled_finite": chk,
+                  "overlap": "none: the gather follows the callback (DESIGN.md section 6)"}
+        out = mine
+
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_k_bgemm.json")))
@@ -285,6 +329,8 @@ def main():
                 (2.0 * (-(-n // 64) * 64) ** 2 * (-(-(Nk - 1) // 128) * 128) * (m + 1) * (m + 1) * terms * args.steps)
                 if args.callback == "jacobian" else fl_sweep),
         }
+        if gather is not None:
+            line["gather"] = gather
         if world == 1 and args.callback == "jacobian" and not args.no_other_callbacks:
             # the other callbacks of the same problem, same protocol (3 untimed + 5 timed calls each): reported for
             # context (SURVEY.md §8d lists them next to the headline), never part of `value`

@@ -34,6 +34,40 @@ def allgather_slabs(local, lens, group=None):
     return torch.cat([out[r * mx:r * mx + lens[r]] for r in range(world)])
 
 
+def slab_layout(lo, n, group=None):
+    """Every rank's (offset, length) of one value vector, from each rank's dto_shard_info entry."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    pairs = [None] * world
+    dist.all_gather_object(pairs, (int(lo), int(n)), group=group)
+    return pairs
+
+
+def gather_slabs_inplace(full, layout, group=None):
+    """All-gather of knot-range slabs WITHOUT staging copies: `full` is the whole value vector (allocated on every rank),
+    rank r's engine has written its slab straight into full[lo_r : lo_r + n_r] (the `*_dev` entry points take the slice's
+    pointer), and this call fills in the other ranks' slices.
+
+    Equal slab lengths (and slabs laid out back to back) go through ONE all_gather_into_tensor on the vector itself; the
+    general case (first and last rank own one boundary column block more or less) is one in-place broadcast per rank --
+    the same bytes over the same links as a ring all-gather, no padding, no concatenation.  Backend "nccl" is RCCL over
+    xGMI on the GPU box; "gloo" serves the CPU and one-device rehearsals."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(layout) == world
+    lens = {n for _, n in layout}
+    contiguous = all(layout[r][0] == layout[0][0] + r * layout[0][1] for r in range(world))
+    if len(lens) == 1 and contiguous and (dist.get_backend(group) == "nccl" or not full.is_cuda):
+        lo0, n = layout[0]
+        dist.all_gather_into_tensor(full[lo0:lo0 + world * n], full[layout[rank][0]:layout[rank][0] + n], group=group)
+        return full
+    for r, (lo, n) in enumerate(layout):
+        if n:
+            dist.broadcast(full[lo:lo + n], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+    return full
+
+
 def allreduce_sum(t, group=None):
     import torch.distributed as dist
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

@@ -46,6 +46,13 @@ def _worker(rank, world, port, q):
             dist.all_gather_object(lens, int(n))
             got = dto_amd.distributed.allgather_slabs(local, lens)
             ok &= bool(np.array_equal(got.numpy(), full[key]))
+            # the in-place form: the rank's slab sits in its slice of the full vector, the gather fills in the rest
+            vec = torch.full((full[key].size,), float("nan"), dtype=torch.float64)
+            vec[a:a + n] = local
+            layout = dto_amd.distributed.slab_layout(a, n)
+            assert layout[rank] == (a, n) and sum(x[1] for x in layout) == full[key].size
+            dto_amd.distributed.gather_slabs_inplace(vec, layout)
+            ok &= bool(np.array_equal(vec.numpy(), full[key]))
         # constraint rows: scatter the local buffer back through the row segments, then sum over ranks
         st, ln = ev.shard_rows()
         g = torch.zeros(ev.n_constraints, dtype=torch.float64)
