@@ -132,6 +132,46 @@ def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
     return out
 
 
+def measure_gather(args, dto_amd, torch, dist, ev, dev, Z, stream, fence, N_total, mu):
+    """configs[3]'s data path: every rank holds the WHOLE value vector; its engine writes the rank's slab straight into its
+    slice, the other slices arrive by the in-place all-gather (dto_amd.distributed.gather_slabs_inplace: RCCL over xGMI
+    with backend nccl; no padded copy, no concatenation).  Times K steps of callback + gather and K gathers alone."""
+    sh = ev.shard
+    lo, ln = (sh.jac_lo, sh.jac_len) if args.callback == "jacobian" else (sh.hess_lo, sh.hess_len)
+    total = ev.n_jacobian_entries if args.callback == "jacobian" else ev.n_hessian_entries
+    full = torch.empty(total, dtype=torch.float64, device=dev)
+    layout = dto_amd.distributed.slab_layout(lo, ln)
+    mine = full[lo:lo + ln]
+    if args.callback == "jacobian":
+        gstep = lambda: ev.eval_jacobian_dev(Z.data_ptr(), mine.data_ptr(), stream)
+    else:
+        gstep = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), mine.data_ptr(), stream)
+    for _ in range(max(1, args.warmup)):
+        gstep()
+        dto_amd.distributed.gather_slabs_inplace(full, layout)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gstep()
+        dto_amd.distributed.gather_slabs_inplace(full, layout)
+    fence()
+    t_both = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dto_amd.distributed.gather_slabs_inplace(full, layout)
+    fence()
+    t_gather = time.perf_counter() - t0
+    tt = torch.tensor([t_both, t_gather], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t_both, t_gather = (float(x) for x in tt.tolist())
+    chk = bool(torch.isfinite(full[::max(1, total // 4096)]).all().item())
+    return {"n_ranks": dist.get_world_size(), "backend": args.backend, "bytes_per_rank_vector": 8.0 * total,
+            "ms_per_step_compute_and_gather": t_both / args.steps * 1e3, "gather_ms": t_gather / args.steps * 1e3,
+            "gather_gbs_per_rank_received": 8.0 * (total - ln) / (t_gather / args.steps) / 1e9,
+            "knot_points_per_s_with_gather": N_total * args.steps / t_both, "sampled_finite": chk,
+            "overlap": "none: the gather follows the callback (DESIGN.md section 6)"}, mine
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,9 +188,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--gather", action="store_true",
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="configs[3] data path: after the compute-only timing, time K more steps in which every rank's slab is "
-                         "written into the full value vector and all-gathered in place (RCCL over xGMI); reported next to `value`")
+                         "written into the full value vector and all-gathered in place (RCCL over xGMI); reported next to `value`. "
+                         "On by default when there is more than one rank")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
     args = ap.parse_args()
 
     import numpy as np
@@ -236,45 +278,15 @@ def main():
     finite = bool(torch.isfinite(out).all().item())
 
     gather = None
-    if args.gather and dist is not None and args.callback in ("jacobian", "hessian"):
-        # every rank holds the WHOLE value vector; its engine writes the rank's slab straight into its slice, the other
-        # slices arrive by the in-place all-gather (dto_amd.distributed.gather_slabs_inplace): no padded copy, no cat
-        lo, ln = (sh.jac_lo, sh.jac_len) if args.callback == "jacobian" else (sh.hess_lo, sh.hess_len)
-        total = ev.n_jacobian_entries if args.callback == "jacobian" else ev.n_hessian_entries
-        gdev = dev if args.backend == "nccl" else dev
-        del out
-        full = torch.empty(total, dtype=torch.float64, device=gdev)
-        layout = dto_amd.distributed.slab_layout(lo, ln)
-        mine = full[lo:lo + ln]
-        if args.callback == "jacobian":
-            gstep = lambda: ev.eval_jacobian_dev(Z.data_ptr(), mine.data_ptr(), stream)
-        else:
-            gstep = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), mine.data_ptr(), stream)
-        for _ in range(max(1, args.warmup)):
-            gstep()
-            dto_amd.distributed.gather_slabs_inplace(full, layout)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            gstep()
-            dto_amd.distributed.gather_slabs_inplace(full, layout)
-        fence()
-        t_both = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dto_amd.distributed.gather_slabs_inplace(full, layout)
-        fence()
-        t_gather = time.perf_counter() - t0
-        tt = torch.tensor([t_both, t_gather], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_both, t_gather = (float(x) for x in tt.tolist())
-        chk = bool(torch.isfinite(full[::max(1, total // 4096)]).all().item())
-        gather = {"n_ranks": dist.get_world_size(), "backend": args.backend, "bytes_per_rank_vector": 8.0 * total,
-                  "ms_per_step_compute_and_gather": t_both / args.steps * 1e3, "gather_ms": t_gather / args.steps * 1e3,
-                  "gather_gbs_per_rank_received": 8.0 * (total - ln) / (t_gather / args.steps) / 1e9,
-                  "knot_points_per_s_with_gather": N_total * args.steps / t_both, "sampled_finite": chk,
-                  "overlap": "none: the gather follows the callback (DESIGN.md section 6)"}
-        out = mine
+    want_gather = args.gather if args.gather is not None else world > 1
+    if want_gather and dist is not None and args.callback in ("jacobian", "hessian"):
+        n_out = out.numel()
+        del out  # its place is taken by the rank's slice of the full vector
+        try:
+            gather, out = measure_gather(args, dto_amd, torch, dist, ev, dev, Z, stream, fence, N_total,
+                                         mu if args.callback == "hessian" else None)
+        except Exception as e:  # the gather is a report next to `value`, never a reason to lose the line
+            gather, out = {"error": repr(e)}, torch.empty(n_out, dtype=torch.float64, device=dev)
 
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
