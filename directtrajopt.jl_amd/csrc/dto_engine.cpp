@@ -682,55 +682,56 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
         launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+        const int nbpad = ((nb + 127) / 128) * 128;
         if (b.use_basis) {
-            const int nbpad = ((nb + 127) / 128) * 128;
             HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * (size_t)3 * cap * npad, st));
             launch_fill(st, w.norms, (int64_t)nb * 4, INFINITY);  // ||A||_1 is not needed: alpha never exceeds d_2
-            for (int r = 0; r < 3; ++r) {
-                launch_basis_coef(st, h->P, b.k, b.basis[r], dZ, int0, nb, nbpad, nullptr);
-                double* cs = w.colsum + (size_t)r * cap * npad;
-                {
-                    ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis[r].cntpad * nb);
-                    launch_basis_gemm(st, npad, nb, nbpad, b.basis[r], w.W[1 + r], cs);
-                }
-                launch_norm_from_colsum(st, npad, nb, cs, w.norms, 1 + r);
+            double* outs[3] = {w.W[1], w.W[2], w.W[3]};
+            double* css[3] = {w.colsum, w.colsum + (size_t)cap * npad, w.colsum + (size_t)2 * cap * npad};
+            launch_basis_coef_multi(st, h->P, b.k, 3, b.basis, dZ, int0, nb, nbpad);
+            {
+                // A^2, A^3, A^4 in one launch (tiles interleaved: the write-bound sets overlap the MFMA-bound one)
+                const double cols = b.basis[0].cntpad + b.basis[1].cntpad + b.basis[2].cntpad;
+                ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * cols * nb);
+                launch_basis_gemm_multi(st, npad, nb, nbpad, 3, b.basis, outs, css);
             }
+            launch_norm_from_colsum_multi(st, npad, nb, 3, css, w.norms);
         } else {
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
+            launch_norm1(st, npad, nb, w);
         }
-        if (!b.use_basis) launch_norm1(st, npad, nb, w);
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 8 * sizeof(int32_t), st));
         launch_expm_params(st, nb, s_ub, w);
         if (c0 == 0) HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
         launch_hump(st, h->P, b.k, dZ, b.d_g1, int0, nb, w.norms, b.d_hump);
-        // the evaluation form and the number of squaring launches are data dependent: read back max/sum of s_k for both
-        // forms (24 bytes); `in_bubble` gives the GPU independent work for the round trip
-        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
-        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        hipEvent_t ev_s = h->ev_chain;
-        HIP_CHECK(hipEventRecord(ev_s, st));
-        if (c0 == 0 && in_bubble) in_bubble();
-        HIP_CHECK(hipEventSynchronize(ev_s));
-        // three products + s3 squarings against two products + s squarings, summed over the chunk; the third product (two
-        // outputs, five epilogue streams: HBM-bound) costs about 1.5 squarings (measured at 256x2000: 1.63 ms against 1.29 ms
-        // per launch, and 2 x 1.50 ms for the two products of the other form)
-        int form = 2 * ((int64_t)hs[1] - (int64_t)hs[5]) > 3 * (int64_t)nb ? 3 : 2;
+        // The evaluation form is decided ON THE DEVICE (k_expm_coef: three products + s3 squarings against two products + s
+        // squarings, summed over the chunk) unless an option pins it, so the factor K of the first product can be
+        // enqueued before the host knows the outcome; the host needs it only for the launch sequence that follows and reads
+        // it back (with the squaring counts, 32 bytes) while the GPU works on K -- `in_bubble` adds more independent work.
         static const int env_form = tune_int("DTO_EXPM_FORM", 0);  // A/B runs
-        if (env_form == 2 || env_form == 3) form = env_form;
-        if (h->expm_form == 2 || h->expm_form == 3) form = h->expm_form;
-        h->last_form = form;
-        launch_expm_coef(st, nb, w, form);
+        int want_form = 0;
+        if (env_form == 2 || env_form == 3) want_form = env_form;
+        if (h->expm_form == 2 || h->expm_form == 3) want_form = h->expm_form;
+        launch_expm_coef(st, nb, w, want_form);
         if (b.use_basis) {
-            const int nbpad = ((nb + 127) / 128) * 128;
             launch_basis_coef(st, h->P, b.k, b.basis_all, dZ, int0, nb, nbpad, w.coef);
             ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis_all.cntpad * nb);
             launch_basis_gemm(st, npad, nb, nbpad, b.basis_all, w.W[5], nullptr);
         } else {
             launch_poly_h3(st, npad, nb, w);
         }
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
+        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        hipEvent_t ev_s = h->ev_chain;
+        HIP_CHECK(hipEventRecord(ev_s, st));
+        if (c0 == 0 && in_bubble) in_bubble();
+        HIP_CHECK(hipEventSynchronize(ev_s));
+        const int form = hs[6];
+        if (form != 2 && form != 3) throw HipError{"propagator chain: the evaluation form did not come back from the device"};
+        h->last_form = form;
         // Y = A^4 K -> (Y + Pa, Y + Pb) in one launch
         { ProfScope ps(h, st, CAT_BGEMM_HORNER, gemm_flops * nb); launch_bgemm_poly(st, npad, nb, w, 3, 5, 4, COEF_PA, 6, COEF_PB); }
         const SlabDest slab{h->P, b.k, int0, vals};  // intervals with s_k = 0: the last product is exp(A_k) itself

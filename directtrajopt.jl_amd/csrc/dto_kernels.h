@@ -167,7 +167,9 @@ void launch_norm1(hipStream_t st, int npad, int nb, const ChainWork& w);
 // 1-norm of matrix `which` only; also folds max_k sqrt(norm) into w.d2max (used when the chain is not run)
 void launch_norm1_one(hipStream_t st, int npad, int nb, const ChainWork& w, int which);
 void launch_expm_params(hipStream_t st, int nb, int s_cap, const ChainWork& w);
-// coefficient table (and w.s) for the chosen form: 2 = two products (degree 16), 3 = three products (order 26)
+// Coefficient table (and w.s) for the evaluation form: 2 = two products (degree 16), 3 = three products (order 26),
+// 0 = decided ON THE DEVICE from the squaring counts k_expm_params left in w.smax (three products when they save more than
+// 1.5 squarings per interval); the form taken lands in w.smax[6] for the host's readback.
 void launch_expm_coef(hipStream_t st, int nb, const ChainWork& w, int form);
 void launch_poly_h3(hipStream_t st, int npad, int nb, const ChainWork& w);
 // where exp(A_k) of the intervals that need no squaring goes: the x_k columns of the Jacobian slab
@@ -377,6 +379,15 @@ void launch_jac_zero(hipStream_t st, const KProb& P, const KBil& B, double* vals
 // colsum (nullable): [nb][npad] accumulators of the column abs-sums of every output matrix (zeroed by
 // the caller); the exact 1-norms then cost no extra pass over the matrices.
 void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum);
+// the same for several basis sets in ONE launch (A^2, A^3, A^4): their tiles are interleaved, so the write-bound sets
+// (few multisets, short K loop) overlap with the MFMA-bound ones instead of running one after the other
+void launch_basis_gemm_multi(hipStream_t st, int npad, int nb, int nbpad, int nsets, const BasisSet* bs, double* const* out,
+                             double* const* colsum);
+// coefficients of several basis sets in one launch
+void launch_basis_coef_multi(hipStream_t st, const KProb& P, const KBil& B, int nsets, const BasisSet* bs, const double* dZ,
+                             int64_t int0, int nb, int nbpad);
+// norms[b*4 + 1 + r] = max column sum of set r, r < nsets (one launch)
+void launch_norm_from_colsum_multi(hipStream_t st, int npad, int nb, int nsets, double* const* colsum, double* norms);
 // norms[b*4 + which] = max_c colsum[b][c]
 void launch_beta_from_norms(hipStream_t st, int nb, const ChainWork& w);
 void launch_hump(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, const double* g1, int64_t int0, int nb,

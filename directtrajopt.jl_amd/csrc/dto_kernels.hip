@@ -178,6 +178,116 @@ void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* col
                              unsigned long long* d2max) {
     hipLaunchKernelGGL(k_norm_from_colsum, dim3(nb), dim3(64), 0, st, npad, nb, colsum, norms, which, d2max);
 }
+struct BasisMulti {
+    int nsets;
+    BasisSet bs[3];
+    double* out[3];
+    double* colsum[3];
+};
+// Several basis sets in one grid: block -> (set, tile) with the set index fastest, so neighbouring workgroups mix the
+// write-bound sets with the MFMA-bound ones.
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::THREADS, 2) k_basis_gemm_multi(int npad, int nb, BasisMulti M) {
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
+    const int which = blockIdx.x % M.nsets, tile = blockIdx.x / M.nsets;
+    BasisSet bs = M.bs[0];
+    double* out = M.out[0];
+    double* colsum = M.colsum[0];
+#pragma unroll
+    for (int q = 1; q < 3; ++q)
+        if (q == which) { bs = M.bs[q]; out = M.out[q]; colsum = M.colsum[q]; }
+    const int64_t nn = (int64_t)npad * npad;
+    const int row_tiles = (int)(nn / TM);
+    const int rt = tile % row_tiles, ct = tile / row_tiles;
+    GemmAccS<Cfg> acc;
+    acc.zero();
+    gemm_accumulate_s<Cfg>(acc, bs.S + (int64_t)rt * TM, (int)nn, bs.coef + (int64_t)ct * TN * bs.cntpad, bs.cntpad,
+                           bs.cntpad, nullptr, smem);
+    GemmCoordS<Cfg> co;
+    const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
+#pragma unroll
+    for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = col0 + 16 * tj + 4 * r;
+            double asum = 0.0;
+#pragma unroll
+            for (int ti = 0; ti < Cfg::MT; ++ti) {
+                if (col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
+                asum += fabs(acc.v[ti][tj][r]);
+            }
+            static_assert(Cfg::WTM == 64, "column sums assume 64-row wave tiles");
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
+            if ((threadIdx.x & 15) == 0 && col < nb)
+                atomicAdd(&colsum[(int64_t)col * npad + (rt * TM + (co.row_base & ~63)) / npad], asum);
+        }
+}
+void launch_basis_gemm_multi(hipStream_t st, int npad, int nb, int nbpad, int nsets, const BasisSet* bs, double* const* out,
+                             double* const* colsum) {
+    const int64_t nn = (int64_t)npad * npad;
+    using C = GemmShape<128, 128, 2, 4, 16>;
+    BasisMulti M{};
+    M.nsets = nsets;
+    for (int q = 0; q < nsets; ++q) { M.bs[q] = bs[q]; M.out[q] = out[q]; M.colsum[q] = colsum[q]; }
+    hipLaunchKernelGGL((k_basis_gemm_multi<C>), dim3((unsigned)((nn / 128) * (nbpad / 128) * nsets)), dim3(C::THREADS), 0, st, npad, nb, M);
+}
+__global__ void k_basis_coef_multi(KProb P, KBil B, BasisMulti M, const double* __restrict__ Z, int64_t int0, int nb) {
+    const int b = blockIdx.x;
+    BasisSet bs = M.bs[0];
+#pragma unroll
+    for (int q = 1; q < 3; ++q)
+        if (q == (int)blockIdx.y) bs = M.bs[q];
+    double* c = bs.coef + (int64_t)b * bs.cntpad;
+    if (b >= nb) {
+        for (int a = threadIdx.x; a < bs.cntpad; a += blockDim.x) c[a] = 0.0;
+        return;
+    }
+    const double* zk = Z + (int0 + b) * P.z;
+    const double dt = zk[P.dt_idx];
+    for (int a = threadIdx.x; a < bs.cntpad; a += blockDim.x) {
+        double v = 0.0;
+        if (a < bs.cnt) {
+            v = 1.0;
+            for (int i = 0; i < bs.r; ++i) {
+                const int g = bs.idx[a * bs.r + i];
+                v *= dt;
+                if (g > 0) v *= zk[B.u_off + g - 1];
+            }
+        }
+        c[a] = v;
+    }
+}
+void launch_basis_coef_multi(hipStream_t st, const KProb& P, const KBil& B, int nsets, const BasisSet* bs, const double* dZ,
+                             int64_t int0, int nb, int nbpad) {
+    BasisMulti M{};
+    M.nsets = nsets;
+    for (int q = 0; q < nsets; ++q) M.bs[q] = bs[q];
+    hipLaunchKernelGGL(k_basis_coef_multi, dim3(nbpad, nsets), dim3(128), 0, st, P, B, M, dZ, int0, nb);
+}
+__global__ void k_norm_from_colsum_multi(int npad, int nb, BasisMulti M, double* __restrict__ norms) {
+    const int b = blockIdx.x, which = blockIdx.y;
+    const double* colsum = M.colsum[0];
+#pragma unroll
+    for (int q = 1; q < 3; ++q)
+        if (q == which) colsum = M.colsum[q];
+    double m = 0.0, bad = 0.0;
+    for (int c = threadIdx.x; c < npad; c += 64) {
+        const double v = colsum[(int64_t)b * npad + c];
+        m = fmax(m, v);
+        if (!(v == v)) bad = 1.0;  // NaN anywhere in the matrix must reach the scaling decision (fmax drops it)
+    }
+    m = wave_max(m);
+    bad = wave_max(bad);
+    if (threadIdx.x == 0) norms[b * 4 + 1 + which] = bad > 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : m;
+}
+void launch_norm_from_colsum_multi(hipStream_t st, int npad, int nb, int nsets, double* const* colsum, double* norms) {
+    BasisMulti M{};
+    M.nsets = nsets;
+    for (int q = 0; q < nsets; ++q) M.colsum[q] = colsum[q];
+    hipLaunchKernelGGL(k_norm_from_colsum_multi, dim3(nb, nsets), dim3(64), 0, st, npad, nb, M, norms);
+}
 void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisSet& bs, double* out, double* colsum) {
     const int64_t nn = (int64_t)npad * npad;
     // 8 waves of 64x32 per 128x128 tile: the K loop is only 1..8 panels long, more waves hide its prologue and the
@@ -240,7 +350,8 @@ __global__ void __launch_bounds__(256) k_jac_zero(KProb P, KBil B, double* __res
     const bool skipE = has_own && (int64_t)blockIdx.x < P.n_int;
     const int64_t e_lo = (int64_t)B.pre * cnt + (has_prev ? B.n : 0);  // offset of the E rows inside an x column
     // 16-byte stores over the 16-byte-aligned interior of [lo, hi), scalar stores at an odd head / tail; a column holds
-    // a few hundred entries, so each half of the workgroup takes its own column
+    // a few hundred entries, so each half of the workgroup takes its own column (one wavefront per column with
+    // non-temporal stores and eight workgroups per knot was measured 14 % slower)
     const int lane = threadIdx.x & 127, half = threadIdx.x >> 7;
     auto zero_range = [&](int64_t lo, int64_t hi) {
         if (hi <= lo) return;
@@ -436,6 +547,7 @@ k_bgemm(BGemmArgs a) {
             const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
             c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
             M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn; M4 = a.M4 + b * nn;
+
             if (epi_dual(EPI)) {
                 const double* ef = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base2;
                 e0 = ef[0]; e1 = ef[1]; e2 = ef[2]; e3 = ef[3]; e4 = ef[4];
@@ -733,6 +845,11 @@ __global__ void k_expm_params(int nb, int s_cap, ChainWork w) {
 // of sigma = 2^-s so that the kernels work on the unscaled A, A^2, A^3, A^4.
 __global__ void k_expm_coef(int nb, ChainWork w, int form) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // form 0: decided here, by every thread alike, from the chunk's squaring counts (k_expm_params): three products + s3
+    // squarings against two products + s squarings, summed over the chunk; the third product (two outputs, five epilogue
+    // streams: HBM-bound) costs about 1.5 squarings
+    if (form == 0) form = 2 * ((int64_t)w.smax[1] - (int64_t)w.smax[5]) > 3 * (int64_t)nb ? 3 : 2;
+    if (b == 0) w.smax[6] = form;
     if (b >= nb) return;
     int s = w.s[b];
     if (form == 3) { s = w.s3[b]; w.s[b] = s; }
