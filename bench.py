@@ -63,7 +63,7 @@ def cpu_baseline(prob, n, m, N, budget_s=20.0):
     The reference is Julia and cannot run here, so the baseline is the C restatement of its ALGORITHM
     (oracle/dto_ref_costmodel.c: serial walk over the intervals, ForwardDiff-style forward mode over the 2z inputs in
     chunks of 12 through the truncated-Taylor `expv`, bilinear_integrator.jl:81,111-131): W single-threaded processes (W =
-    the CPUs this process may use = the box's share for one GPU) each take every W-th interval of the same synthetic
+    the CPUs this process may use, at most 16 = the box's share for one GPU) each take every W-th interval of the same synthetic
     problem for `budget_s`/2 seconds; the same on ONE core; and, for context, the repository's own oracle (scipy
     expm + expm_frechet per knot, a different and much cheaper algorithm) on W cores.  Knots are independent, so the
     W-process figure is the CPU's parallel rate."""
@@ -73,7 +73,7 @@ def cpu_baseline(prob, n, m, N, budget_s=20.0):
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    W = max(1, min(avail, N - 1))
+    W = max(1, min(16, avail, N - 1))  # 16 = the box's CPU share for one GPU, whatever the affinity mask shows
     exe = build_ref_costmodel()
     G = prob.integrators[0].G
     z = prob.trajectory.dim
@@ -290,7 +290,7 @@ def main():
 
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_k_bgemm.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_k_bgemm.json")))
         if (n, Nk, args.callback) == (256, 2000, "jacobian"):
             traffic, traffic_src = tj["avg_per_launch_bytes"], tj["source"]
     except Exception:
