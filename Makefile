@@ -14,13 +14,16 @@ $(CSRC)/dto_kernels.o: $(CSRC)/dto_kernels.hip $(CSRC)/dto_kernels.h $(CSRC)/dto
 $(CSRC)/dto_small.o: $(CSRC)/dto_small.hip $(CSRC)/dto_kernels.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(CSRC)/dto_tdb.o: $(CSRC)/dto_tdb.hip $(CSRC)/dto_kernels.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(CSRC)/dto_sweep_fused.o: $(CSRC)/dto_sweep_fused.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/dto_engine.o: $(CSRC)/dto_engine.cpp $(CSRC)/dto_kernels.h include/dto_engine.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_small.o $(CSRC)/dto_sweep_fused.o $(CSRC)/dto_engine.o
+$(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_small.o $(CSRC)/dto_sweep_fused.o $(CSRC)/dto_tdb.o $(CSRC)/dto_engine.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 clean:

@@ -27,6 +27,7 @@ from .host.problem import (  # noqa: F401
     NonlinearGlobalConstraint,
     HostIntegrator,
     TimeDependentBilinearIntegrator,
+    ModulatedGenerators,
     ket_fidelity_factor,
     NonlinearKnotPointConstraint,
     DirectTrajOptProblem,

@@ -122,6 +122,14 @@ struct ExtSlot {
     double* d[3] = {nullptr, nullptr, nullptr};
 };
 
+// DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR: evaluated by dto_tdb.hip into per-interval blocks, placed like an external integrator
+struct TdbHost {
+    KTdb k{};
+    KExtInt place{};
+    double *d_vals = nullptr, *d_jac = nullptr, *d_hess = nullptr, *d_scratch = nullptr;
+    size_t stride = 0;
+};
+
 struct ProfRec {
     hipEvent_t a, b;
     int cat;
@@ -152,6 +160,7 @@ struct dto_handle {
     std::vector<KObj> obj;
     std::vector<ExtObjHost> ext_obj;
     std::vector<KExtInt> ext_int;  // DTO_INTEGRATOR_EXTERNAL, slot = index
+    std::vector<TdbHost> tdb;      // DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR
     std::vector<ExtSlot> ext;      // external integrators, then constraints, then objectives, each in list order
     int n_ext_int = 0, n_ext_con = 0, n_ext_obj = 0;
     std::vector<int64_t> tail_colptr, tail_rows;  // Hessian entries in global-variable columns (CSC tail)
@@ -883,6 +892,15 @@ const double* ext_upload(dto_handle* h, int slot, int which, hipStream_t st) {
     return e.d[which];
 }
 
+// blocks of a device-evaluated time-dependent bilinear integrator: the owned intervals for the defect; for the Jacobian /
+// Hessian also the interval left of the first owned knot, whose z_{k+1} half lands in that knot's columns
+void tdb_eval(dto_handle* h, TdbHost& t, const double* dZ, const double* dmu, int need, hipStream_t st) {
+    const KProb& P = h->P;
+    const int64_t lo = need == 0 ? P.kn_lo : std::max<int64_t>(0, P.kn_lo - 1);
+    const int64_t hi = need == 0 ? P.kn_lo + P.n_int : std::min<int64_t>(P.K, P.kn_lo + P.n_knots);
+    HIP_CHECK(launch_tdb(st, P, t.k, dZ, dmu, need, lo, hi - lo, t.d_vals, t.d_jac, t.d_hess, t.d_scratch, t.stride));
+}
+
 void do_objective(dto_handle* h, const double* dZ, double* df, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(df, 0, sizeof(double), st));
     for (auto& o : h->obj) launch_objective(st, h->P, o, dZ, h->d_partial, df);
@@ -929,6 +947,8 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
     for (auto& d : h->der) launch_cons_derivative(st, h->P, d, dZ, dg);
     for (size_t i = 0; i < h->ext_int.size(); ++i)
         if (h->P.n_int > 0) launch_extint_cons(st, h->P, h->ext_int[i], ext_upload(h, (int)i, 0, st), dg);
+    for (auto& t : h->tdb)
+        if (h->P.n_int > 0) { tdb_eval(h, t, dZ, nullptr, 0, st); launch_extint_cons(st, h->P, t.place, t.d_vals, dg); }
     for (auto& c : h->con) {
         if (!c.external) launch_cons_knot(st, h->P, c.k, dZ, dg);
         else if (c.k.n_times > 0) launch_ext_cons(st, c.k, ext_upload(h, c.ext_slot, 0, st), dg);
@@ -996,6 +1016,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
     for (auto& d : h->der) launch_jac_derivative(st, h->P, d, dZ, dvals);
     for (size_t i = 0; i < h->ext_int.size(); ++i)
         launch_extint_jac(st, h->P, h->ext_int[i], ext_upload(h, (int)i, 1, st), dvals);
+    for (auto& t : h->tdb) { tdb_eval(h, t, dZ, nullptr, 1, st); launch_extint_jac(st, h->P, t.place, t.d_jac, dvals); }
     for (auto& c : h->con) {
         if (!c.external) launch_jac_knot(st, h->P, c.k, dZ, dvals);
         else if (c.k.n_times > 0) launch_ext_jac(st, c.k, ext_upload(h, c.ext_slot, 1, st), dvals);
@@ -1064,6 +1085,10 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             }
         } else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) {
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
+        } else if (h->integ_kind[i] == DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR) {
+            TdbHost& t = h->tdb[h->integ_index[i]];
+            tdb_eval(h, t, dZ, dmu, 2, st);
+            launch_extint_hess(st, h->P, t.place, t.d_hess, dH);
         } else {  // the caller's blocks already carry mu_k (eval_hessian_of_lagrangian(integrator, traj, mu_slice))
             const int e = h->integ_index[i];
             launch_extint_hess(st, h->P, h->ext_int[e], ext_upload(h, e, 2, st), dH);
@@ -1270,6 +1295,30 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 k.d = s.x_dim; k.x_off = s.x_off; k.xdot_off = s.u_off; k.pre = pre; k.row_off = row;
                 h->integ_index.push_back((int)h->der.size());
                 h->der.push_back(k);
+            } else if (s.kind == DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR) {
+                if (s.u_dim < 0 || s.u_dim > MAX_DRIVES) throw HipError{"time-dependent bilinear integrator: supports 0..7 drives"};
+                if (s.u_dim > 0 && (s.u_off < 0 || s.u_off + s.u_dim > d->z)) throw HipError{"time-dependent bilinear integrator: bad control range"};
+                if (s.t_off < 0 || s.t_off >= d->z) throw HipError{"time-dependent bilinear integrator: bad time component"};
+                if (s.spline_order != 0 && s.spline_order != 1) throw HipError{"Unsupported spline order (0 or 1)"};
+                if (!s.G || (s.n_mod > 0 && (!s.H || !s.mod_kind || !s.mod_omega))) throw HipError{"time-dependent bilinear integrator: G / H / modulation arrays are null"};
+                TdbHost t;
+                t.k.n = s.x_dim; t.k.m = s.u_dim; t.k.x_off = s.x_off; t.k.u_off = s.u_off; t.k.t_off = s.t_off;
+                t.k.order = s.spline_order; t.k.substeps = s.substeps; t.k.nmod = s.n_mod; t.k.row_off = row;
+                if (!tdb_supported(t.k)) throw HipError{"time-dependent bilinear integrator: outside the device kernel's range (1..64 states, substeps >= 1, coefficient table)"};
+                for (int c = 0; c < s.n_mod; ++c)
+                    if (s.mod_kind[c] != 1 && s.mod_kind[c] != 2) throw HipError{"time-dependent bilinear integrator: mod_kind is 1 (cos) or 2 (sin)"};
+                t.place.d = s.x_dim; t.place.pre = pre; t.place.row_off = row;
+                if (!sonly) {
+                    const size_t nn = (size_t)s.x_dim * s.x_dim, m1 = (size_t)s.u_dim + 1;
+                    t.k.G = own(h, dupload(std::vector<double>(s.G, s.G + m1 * nn)));
+                    if (s.n_mod > 0) {
+                        t.k.H = own(h, dupload(std::vector<double>(s.H, s.H + (size_t)s.n_mod * m1 * nn)));
+                        t.k.mod_kind = own(h, dupload(std::vector<int32_t>(s.mod_kind, s.mod_kind + s.n_mod)));
+                        t.k.mod_omega = own(h, dupload(std::vector<double>(s.mod_omega, s.mod_omega + s.n_mod)));
+                    }
+                }
+                h->integ_index.push_back((int)h->tdb.size());
+                h->tdb.push_back(t);
             } else if (s.kind == DTO_INTEGRATOR_EXTERNAL) {
                 KExtInt e{};
                 e.d = s.x_dim; e.pre = pre; e.row_off = row;
@@ -1430,6 +1479,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             const int dd = h->integ_dim[i];
             if (h->integ_kind[i] == DTO_INTEGRATOR_BILINEAR) h->bil[h->integ_index[i]].k.lrow_off = lrow;
             else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) h->der[h->integ_index[i]].lrow_off = lrow;
+            else if (h->integ_kind[i] == DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR) h->tdb[h->integ_index[i]].place.lrow_off = lrow;
             else h->ext_int[h->integ_index[i]].lrow_off = lrow;
             if (P.n_int > 0) h->row_segments.emplace_back(h->integ_row_off[i] + P.kn_lo * dd, P.n_int * dd);
             lrow += P.n_int * dd;
@@ -1606,6 +1656,16 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         HIP_CHECK(hipHostMalloc((void**)&h->h_stats, sizeof(int32_t) * 4 * std::max<size_t>(h->bil.size(), 1)));
         memset(h->h_stats, 0, sizeof(int32_t) * 4 * std::max<size_t>(h->bil.size(), 1));
 
+        // device buffers of the time-dependent bilinear integrators: blocks indexed by the global interval (like the
+        // host-evaluated integrators' arrays), one scratch slab per interval this handle evaluates
+        for (auto& t : h->tdb) {
+            const size_t n = t.k.n, z = h->z, K = (size_t)h->K;
+            t.d_vals = own(h, dalloc<double>(K * n));
+            t.d_jac = own(h, dalloc<double>(K * n * 2 * z));
+            if (d->eval_hessian) t.d_hess = own(h, dalloc<double>(K * 4 * z * z));
+            t.stride = (tdb_scratch_doubles(t.k, d->eval_hessian ? 2 : 1) + 1) & ~(size_t)1;
+            t.d_scratch = own(h, dalloc<double>(t.stride * (size_t)(P.n_knots + 1)));
+        }
         // per-bilinear workspaces + generator product norms (for the step-budget bounds)
         for (auto& b : h->bil) {
             const int m = b.k.m;
@@ -1912,7 +1972,7 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
     bool mfree = h->eval_hessian != 0 || transpose == 0;  // the adjoint sweep buffers exist only with eval_hessian
     for (auto& b : h->bil) mfree = mfree && !b.small && (transpose == 0 || b.ad.S != nullptr) && b.k.m + 2 <= MAX_TYPES;
     for (auto& c : h->con) mfree = mfree && !c.external;  // external blocks are placed into the value slab
-    mfree = mfree && h->ext_int.empty();
+    mfree = mfree && h->ext_int.empty() && h->tdb.empty();
     static const bool mfree_on = tune_int("DTO_JV_MATRIX_FREE", 1) != 0;
     if (mfree && mfree_on) {
         const int64_t n_in = transpose ? h->n_cons : h->n_vars, n_out = transpose ? h->n_vars : h->n_cons;

@@ -296,6 +296,22 @@ void launch_extint_cons(hipStream_t st, const KProb& P, const KExtInt& E, const 
 void launch_extint_jac(hipStream_t st, const KProb& P, const KExtInt& E, const double* blocks, double* vals);
 void launch_extint_hess(hipStream_t st, const KProb& P, const KExtInt& E, const double* blocks, double* H);
 
+// TimeDependentBilinearIntegrator with a parametrised generator family, evaluated on the device (dto_tdb.hip): fills the same
+// per-interval blocks as a host-evaluated integrator, which k_extint_* then place
+struct KTdb {
+    int32_t n, m, x_off, u_off, t_off, order, substeps, nmod;
+    int64_t row_off;             // 0-based global row offset of the integrator (for mu)
+    const double* G;             // (m+1) compact n x n matrices, column-major
+    const double* H;             // [nmod][(m+1)] compact n x n matrices
+    const int32_t* mod_kind;     // [nmod] 1 = cos(omega t), 2 = sin(omega t)
+    const double* mod_omega;     // [nmod]
+};
+bool tdb_supported(const KTdb& T);
+size_t tdb_scratch_doubles(const KTdb& T, int need);
+// blocks of intervals i_lo .. i_lo + count - 1 (global, 0-based) into vals [K][n], jac [K][2z][n], hess [K][2z][2z]
+hipError_t launch_tdb(hipStream_t st, const KProb& P, const KTdb& T, const double* dZ, const double* dmu, int need, int64_t i_lo,
+                      int64_t count, double* vals, double* jac, double* hess, double* scratch, size_t scratch_stride);
+
 // host-evaluated knot terms (DTO_CONSTRAINT_EXTERNAL / DTO_OBJECTIVE_EXTERNAL_KNOT): scatter of caller-supplied blocks
 void launch_ext_cons(hipStream_t st, const KCon& C, const double* vals, double* g);
 void launch_ext_jac(hipStream_t st, const KCon& C, const double* blocks, double* vals);

@@ -1,0 +1,260 @@
+// dto_tdb.hip -- device propagator of the TimeDependentBilinearIntegrator for a PARAMETRISED generator family
+// (reference: src/integrators/time_dependent_bilinear_integrator.jl:60-244).
+//
+// The reference integrates  dx/dtau = dt_k G(u(tau), t_k + tau dt_k) x  on tau in [0, 1] with an arbitrary Julia closure
+// G(u, t) (adaptive Tsit5, differentiated through the solver by ForwardDiff).  A closure cannot cross the C ABI; what can is
+// the family that covers the reference's own uses (carrier-modulated drives, rotating-frame terms, its test
+// G(a) + 0.1 cos(t) I):
+//
+//     G(u, t) = sum_{j=0..m} ubar_j ( G_j + sum_c phi_c(t) H_cj ),   ubar_0 = 1,  phi_c(t) = cos(omega_c t) | sin(omega_c t)
+//
+// with the controls held (spline order 0) or linearly interpolated to u_{k+1} (order 1).  One workgroup per interval runs
+// classical RK4 with a fixed number of sub-steps on the state TOGETHER with its exact forward sensitivities, so that the
+// Jacobian block and the Hessian of mu_k' f are the derivatives of the discrete map itself (for an explicit Runge-Kutta
+// method with fixed steps, differentiating the scheme equals applying the scheme to the variational equations):
+//
+//     parameters theta = [u_k (m), t_k, dt_k, u_{k+1} (m, order 1 only)]   -- the state x_k enters linearly through Phi
+//     columns          x, Phi (n), x_b (p), Phi_b (n p), x_ab (p (p+1) / 2),          each of length n
+//     right-hand side  (M y)_0 = M0 y0,  (M y)_b = M0 y_b + M_b y0,  (M y)_ab = M0 y_ab + M_a y_b + M_b y_a + M_ab y0
+//
+// where M = dt_k G(u(tau), t) and its parameter derivatives M_b, M_ab are linear combinations of the shared matrices G_j, H_cj
+// (formed once per stage).  Outputs are the per-interval dense blocks of a generic integrator -- defect (n), Jacobian block
+// (n x 2z), Hessian block of mu_k' f (2z x 2z) -- which the engine places with the same kernels as host-evaluated
+// integrators (k_extint_*: by column ownership, so sharded handles need no halo exchange).
+//
+// Bound: this is small-state work (quantum-control systems in a rotating frame have 4..32 states); the kernel keeps its
+// columns in an L2-resident scratch slab per workgroup and is latency-, not bandwidth- or MFMA-bound.
+#include "dto_kernels.h"
+
+namespace dto {
+
+namespace {
+
+constexpr int TDB_MAX_COEFS = 6144;  // (1 + p + p (p+1)/2) * (m+1) * (1 + nmod) must fit (checked by tdb_supported)
+
+__device__ __forceinline__ int pair_idx(int a, int b, int p) {  // a <= b < p, row-major upper triangle
+    return a * p - a * (a - 1) / 2 + (b - a);
+}
+
+struct TdbArgs {
+    KProb P;
+    KTdb T;
+    const double* Z;
+    const double* mu;
+    int need;          // 0 defect, 1 + Jacobian block, 2 + Hessian block
+    int64_t i_lo;      // first interval (global, 0-based) of this launch
+    double* vals;      // [K][n]
+    double* jac;       // [K][2z][n]
+    double* hess;      // [K][2z][2z]
+    double* scratch;
+    int64_t scratch_stride;
+};
+
+__global__ void __launch_bounds__(256) k_tdb(TdbArgs a) {
+    const int n = a.T.n, m = a.T.m, z = a.P.z, nmod = a.T.nmod, order = a.T.order;
+    const int p = m + 2 + (order ? m : 0);
+    const int need = a.need;
+    const int64_t kn = a.i_lo + blockIdx.x;
+    const double* zk = a.Z + kn * z;
+    const double* zk1 = zk + z;
+    const double tk = zk[a.T.t_off], dt = zk[a.P.dt_idx];
+    const int tid = threadIdx.x;
+    // column layout
+    const int c_x = 0, c_phi = 1, c_xb = 1 + n, c_phib = 1 + n + p, c_xab = 1 + n + p + n * p;
+    const int C = need == 0 ? 1 : (need == 1 ? 1 + n + p : 1 + n + p + n * p + p * (p + 1) / 2);
+    const int nM = need == 0 ? 1 : (need == 1 ? 1 + p : 1 + p + p * (p + 1) / 2);
+    double* S = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
+    double* Y = S;
+    double* ACC = Y + (int64_t)C * n;
+    double* TA = ACC + (int64_t)C * n;
+    double* TB = TA + (int64_t)C * n;
+    double* MJ = TB + (int64_t)C * n;   // [nM][n*n] column-major jets of M
+    const int nn = n * n;
+    const int Q = (m + 1) * (1 + nmod);  // shared matrices B_q, q = j * (1 + nmod) + c; c = 0: G_j, c >= 1: H_{c-1, j}
+    auto Bq = [&](int j, int c) { return c == 0 ? a.T.G + (int64_t)j * nn : a.T.H + ((int64_t)(c - 1) * (m + 1) + j) * nn; };
+    __shared__ double coefs[TDB_MAX_COEFS];  // [nM][Q] scalar coefficient of B_q in each jet of M at the current stage time
+
+    // initial values: x = x_k, Phi = I, everything else 0
+    for (int e = tid; e < C * n; e += 256) {
+        const int c = e / n, r = e - c * n;
+        double v = 0.0;
+        if (c == c_x) v = zk[a.T.x_off + r];
+        else if (need >= 1 && c >= c_phi && c < c_phi + n) v = (c - c_phi == r) ? 1.0 : 0.0;
+        Y[e] = v;
+    }
+    __syncthreads();
+
+    const double h = 1.0 / a.T.substeps;
+    for (int step = 0; step < a.T.substeps; ++step) {
+        for (int stage = 0; stage < 4; ++stage) {
+            const double tau = (step + (stage == 0 ? 0.0 : (stage == 3 ? 1.0 : 0.5))) * h;
+            const double* IN = stage == 0 ? Y : (stage == 2 ? TB : TA);
+            // ---- jets of M(tau) = dt * sum_j a_j(tau) (G_j + sum_c phi_c(t) H_cj),  t = t_k + tau dt: first the scalar
+            // coefficient of every shared matrix B_q in every jet (value / first / second derivative), then the matrices
+            for (int e = tid; e < nM * Q; e += 256) {
+                const int which = e / Q, q = e - which * Q;
+                const int j = q / (1 + nmod), c = q - j * (1 + nmod);
+                // which: 0 value; 1 + b first derivative; 1 + p + pair(a, b) second derivative
+                int b1 = -1, b2 = -1;
+                if (which >= 1 && which <= p) b1 = which - 1;
+                else if (which > p) {
+                    int rem = which - 1 - p, aa = 0;
+                    while (rem >= p - aa) { rem -= p - aa; ++aa; }
+                    b1 = aa; b2 = aa + rem;
+                }
+                // a_j and its derivative slots: wk = d a_j / d u_kj, wk1 = d a_j / d u_{k+1,j}
+                double aj = 1.0, wk = 0.0, wk1 = 0.0;
+                if (j >= 1) {
+                    const double uk = zk[a.T.u_off + j - 1];
+                    if (order) { const double uk1 = zk1[a.T.u_off + j - 1]; aj = (1.0 - tau) * uk + tau * uk1; wk = 1.0 - tau; wk1 = tau; }
+                    else { aj = uk; wk = 1.0; }
+                }
+                double ph = 1.0, ph1 = 0.0, ph2 = 0.0;
+                if (c >= 1) {
+                    const double om = a.T.mod_omega[c - 1], arg = om * (tk + tau * dt);
+                    const double cs = cos(arg), sn = sin(arg);
+                    if (a.T.mod_kind[c - 1] == 1) { ph = cs; ph1 = -om * sn; ph2 = -om * om * cs; }
+                    else { ph = sn; ph1 = om * cs; ph2 = -om * om * sn; }
+                }
+                // s = dt * a_j * phi(t_k + tau dt) and its derivatives; parameter classes: 0 = u_k (drive jj), 1 = t, 2 = dt,
+                // 3 = u_{k+1} (drive jj)
+                auto cls = [&](int b, int& jj) { if (b < m) { jj = b + 1; return 0; } if (b == m) { jj = -1; return 1; }
+                                                 if (b == m + 1) { jj = -1; return 2; } jj = b - m - 1; return 3; };
+                double coef;
+                if (which == 0) coef = dt * aj * ph;
+                else if (b2 < 0) {
+                    int jj; const int k1 = cls(b1, jj);
+                    if (k1 == 0) coef = jj == j ? dt * wk * ph : 0.0;
+                    else if (k1 == 3) coef = jj == j ? dt * wk1 * ph : 0.0;
+                    else if (k1 == 1) coef = dt * aj * ph1;
+                    else coef = aj * ph + dt * aj * tau * ph1;
+                } else {
+                    int j1, j2; const int k1 = cls(b1, j1), k2 = cls(b2, j2);
+                    const bool u1 = k1 == 0 || k1 == 3, u2 = k2 == 0 || k2 == 3;
+                    if (u1 && u2) coef = 0.0;
+                    else if (u1 || u2) {
+                        const int ju = u1 ? j1 : j2, ku = u1 ? k1 : k2, ko = u1 ? k2 : k1;
+                        const double w = ku == 0 ? wk : wk1;
+                        if (ju != j) coef = 0.0;
+                        else coef = ko == 1 ? dt * w * ph1 : w * (ph + dt * tau * ph1);
+                    } else if (k1 == 1 && k2 == 1) coef = dt * aj * ph2;
+                    else if (k1 == 2 && k2 == 2) coef = 2.0 * aj * tau * ph1 + dt * aj * tau * tau * ph2;
+                    else coef = aj * ph1 + dt * aj * tau * ph2;   // (t, dt)
+                }
+                coefs[e] = coef;
+            }
+            __syncthreads();
+            for (int e = tid; e < nM * nn; e += 256) {
+                const int which = e / nn, off = e - which * nn;
+                double acc = 0.0;
+                for (int q = 0; q < Q; ++q) {
+                    const double cf = coefs[which * Q + q];
+                    if (cf != 0.0) acc += cf * Bq(q / (1 + nmod), q % (1 + nmod))[off];
+                }
+                MJ[e] = acc;
+            }
+            __syncthreads();
+            // ---- K = F(IN), then the RK4 update of this stage
+            const double* M0 = MJ;
+            double* OUT = stage == 0 ? TA : (stage == 1 ? TB : (stage == 2 ? TA : Y));
+            const double w_acc = (stage == 0 || stage == 3) ? h / 6.0 : h / 3.0;
+            const double w_tmp = stage == 2 ? h : 0.5 * h;
+            for (int e = tid; e < C * n; e += 256) {
+                const int c = e / n, r = e - c * n;
+                auto mv = [&](const double* M, int col) {   // (M * IN[col])[r]
+                    double s = 0.0;
+                    const double* y = IN + (int64_t)col * n;
+                    for (int k = 0; k < n; ++k) s += M[r + k * n] * y[k];
+                    return s;
+                };
+                double K = mv(M0, c);
+                if (need >= 1 && c >= c_xb && c < c_xb + p) K += mv(MJ + (int64_t)(1 + c - c_xb) * nn, c_x);
+                else if (need >= 2 && c >= c_phib && c < c_phib + n * p) {
+                    const int b = (c - c_phib) / n, i = (c - c_phib) - b * n;
+                    K += mv(MJ + (int64_t)(1 + b) * nn, c_phi + i);
+                } else if (need >= 2 && c >= c_xab) {
+                    int rem = c - c_xab, aa = 0;
+                    while (rem >= p - aa) { rem -= p - aa; ++aa; }
+                    const int bb = aa + rem;
+                    K += mv(MJ + (int64_t)(1 + aa) * nn, c_xb + bb) + mv(MJ + (int64_t)(1 + bb) * nn, c_xb + aa) +
+                         mv(MJ + (int64_t)(1 + p + pair_idx(aa, bb, p)) * nn, c_x);
+                }
+                const double y0 = Y[e];
+                if (stage == 0) { ACC[e] = y0 + w_acc * K; OUT[e] = y0 + w_tmp * K; }
+                else if (stage < 3) { ACC[e] += w_acc * K; OUT[e] = y0 + w_tmp * K; }
+                else OUT[e] = ACC[e] + w_acc * K;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- outputs (blocks of a generic integrator: _integrators.jl:49-77)
+    for (int r = tid; r < n; r += 256) a.vals[kn * n + r] = zk1[a.T.x_off + r] - Y[c_x * n + r];
+    if (need < 1) return;
+    auto zz_of = [&](int b) { return b < m ? a.T.u_off + b : (b == m ? a.T.t_off : (b == m + 1 ? a.P.dt_idx : z + a.T.u_off + (b - m - 2))); };
+    double* J = a.jac + kn * (int64_t)n * 2 * z;
+    for (int e = tid; e < n * 2 * z; e += 256) J[e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, r = e - i * n;
+        J[(int64_t)(a.T.x_off + i) * n + r] = -Y[(int64_t)(c_phi + i) * n + r];
+    }
+    for (int r = tid; r < n; r += 256) J[(int64_t)(z + a.T.x_off + r) * n + r] = 1.0;
+    __syncthreads();
+    // parameter columns ADD (a component may serve twice, e.g. the timestep listed as the time variable)
+    if (tid < n)
+        for (int b = 0; b < p; ++b) J[(int64_t)zz_of(b) * n + tid] -= Y[(int64_t)(c_xb + b) * n + tid];
+    if (need < 2) return;
+    double* Hb = a.hess + kn * (int64_t)4 * z * z;
+    for (int e = tid; e < 4 * z * z; e += 256) Hb[e] = 0.0;
+    __syncthreads();
+    const double* muk = a.mu + a.T.row_off + kn * n;
+    const int ld = 2 * z;
+    // (x_i, theta_b): -mu' dPhi_i/dtheta_b;  (theta_a, theta_b): -mu' x_ab.  One thread per entry; entries that land on the
+    // same (row, col) of the block (coinciding components) are added by the same thread order-independently via atomics.
+    for (int e = tid; e < n * p; e += 256) {
+        const int b = e / n, i = e - b * n;
+        double s = 0.0;
+        for (int r = 0; r < n; ++r) s += muk[r] * Y[(int64_t)(c_phib + b * n + i) * n + r];
+        const int ri = a.T.x_off + i, cb = zz_of(b);
+        atomicAdd(&Hb[ri + (int64_t)ld * cb], -s);
+        atomicAdd(&Hb[cb + (int64_t)ld * ri], -s);
+    }
+    for (int e = tid; e < p * (p + 1) / 2; e += 256) {
+        int rem = e, aa = 0;
+        while (rem >= p - aa) { rem -= p - aa; ++aa; }
+        const int bb = aa + rem;
+        double s = 0.0;
+        for (int r = 0; r < n; ++r) s += muk[r] * Y[(int64_t)(c_xab + e) * n + r];
+        const int ra = zz_of(aa), rb = zz_of(bb);
+        atomicAdd(&Hb[ra + (int64_t)ld * rb], -s);
+        if (aa != bb) atomicAdd(&Hb[rb + (int64_t)ld * ra], -s);
+    }
+}
+
+}  // namespace
+
+bool tdb_supported(const KTdb& T) {
+    const int p = T.m + 2 + (T.order ? T.m : 0);
+    const long nM = 1 + p + (long)p * (p + 1) / 2;
+    return T.n >= 1 && T.n <= 64 && T.nmod >= 0 && T.substeps >= 1 && nM * (T.m + 1) * (1 + T.nmod) <= TDB_MAX_COEFS;
+}
+
+size_t tdb_scratch_doubles(const KTdb& T, int need) {
+    const int n = T.n, m = T.m, p = m + 2 + (T.order ? m : 0);
+    const size_t C = need == 0 ? 1 : (need == 1 ? 1 + n + p : 1 + n + p + (size_t)n * p + (size_t)p * (p + 1) / 2);
+    const size_t nM = need == 0 ? 1 : (need == 1 ? 1 + p : 1 + p + (size_t)p * (p + 1) / 2);
+    return 4 * C * n + nM * (size_t)n * n;
+}
+
+hipError_t launch_tdb(hipStream_t st, const KProb& P, const KTdb& T, const double* dZ, const double* dmu, int need, int64_t i_lo,
+                      int64_t count, double* vals, double* jac, double* hess, double* scratch, size_t scratch_stride) {
+    if (count <= 0) return hipSuccess;
+    TdbArgs a{};
+    a.P = P; a.T = T; a.Z = dZ; a.mu = dmu; a.need = need; a.i_lo = i_lo;
+    a.vals = vals; a.jac = jac; a.hess = hess; a.scratch = scratch; a.scratch_stride = (int64_t)scratch_stride;
+    hipLaunchKernelGGL(k_tdb, dim3((unsigned)count), dim3(P.debug_bad_launch ? 4096 : 256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace dto

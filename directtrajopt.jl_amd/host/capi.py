@@ -8,16 +8,18 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 4
+DTO_ABI_VERSION = 5
 FLAG_GENERAL_PATH_ONLY = 1
-INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL = 1, 2, 3
+INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL, INTEGRATOR_TIME_DEPENDENT_BILINEAR = 1, 2, 3, 4
 OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK, OBJECTIVE_EXTERNAL_GLOBAL = 1, 2, 3, 4, 5, 6, 7
 CONSTRAINT_NORM, CONSTRAINT_SQNORM, CONSTRAINT_EXTERNAL, CONSTRAINT_EXTERNAL_GLOBAL = 1, 2, 3, 4
 
 
 class IntegratorDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("x_off", C.c_int32), ("x_dim", C.c_int32), ("u_off", C.c_int32),
-                ("u_dim", C.c_int32), ("G", c_double_p)]
+                ("u_dim", C.c_int32), ("G", c_double_p),
+                ("t_off", C.c_int32), ("spline_order", C.c_int32), ("substeps", C.c_int32), ("n_mod", C.c_int32),
+                ("mod_kind", c_int32_p), ("mod_omega", c_double_p), ("H", c_double_p)]
 
 
 class ObjectiveDesc(C.Structure):

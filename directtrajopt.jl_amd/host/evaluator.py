@@ -9,7 +9,7 @@ import numpy as np
 from . import capi
 from .capi import library_path, load_library  # noqa: F401
 from .problem import (BilinearIntegrator, CompositeObjective, DerivativeIntegrator, GlobalKnotPointObjective, HostIntegrator,
-                      KnotPointObjective, LinearRegularizer, MinimumTimeObjective, NonlinearGlobalConstraint,
+                      KnotPointObjective, TimeDependentBilinearIntegrator, LinearRegularizer, MinimumTimeObjective, NonlinearGlobalConstraint,
                       NonlinearKnotPointConstraint, NullObjective, QuadraticRegularizer)
 
 
@@ -82,6 +82,18 @@ class Evaluator:
                 integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_BILINEAR, it.x_off, it.x_dim, it.u_off, it.u_dim, _dp(G))
             elif isinstance(it, DerivativeIntegrator):
                 integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_DERIVATIVE, it.x_off, it.x_dim, it.xdot_off, it.x_dim, None)
+            elif isinstance(it, TimeDependentBilinearIntegrator) and it.family is not None:
+                fam = it.family
+                G = np.ascontiguousarray(np.transpose(fam.G, (0, 2, 1)))  # column-major per matrix
+                kinds = np.ascontiguousarray([1 if k == "cos" else 2 for k, _, _ in fam.mods], dtype=np.int32)
+                omegas = np.ascontiguousarray([w for _, w, _ in fam.mods], dtype=np.float64)
+                Hs = (np.ascontiguousarray(np.stack([np.transpose(Hc, (0, 2, 1)) for _, _, Hc in fam.mods]))
+                      if fam.mods else np.zeros(1))
+                keep += [G, kinds, omegas, Hs]
+                integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_TIME_DEPENDENT_BILINEAR, it.x_off, it.x_dim, it.u_off, it.u_dim, _dp(G),
+                                               it.t_off, it.spline_order, it.substeps, len(fam.mods),
+                                               kinds.ctypes.data_as(capi.c_int32_p) if fam.mods else None,
+                                               _dp(omegas) if fam.mods else None, _dp(Hs) if fam.mods else None)
             elif isinstance(it, HostIntegrator):
                 integ[i] = capi.IntegratorDesc(capi.INTEGRATOR_EXTERNAL, 0, it.x_dim, 0, 0, None)
                 self._ext_int.append((it, sum(p.dim for p in prob.integrators[:i])))

@@ -91,17 +91,46 @@ class HostIntegrator:
         return vals, first, second
 
 
+class ModulatedGenerators:
+    """The parametrised generator family the engine integrates ON THE DEVICE (DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR):
+
+        G(u, t) = sum_{j=0..m} ubar_j ( G_j + sum_c phi_c(t) H_cj ),   ubar_0 = 1,  phi_c = cos(omega_c t) or sin(omega_c t)
+
+    ``G``: (m+1, n, n); ``mods``: sequence of (kind, omega, H) with kind "cos" / "sin" and H of shape (m+1, n, n).  The object
+    is also the closure ``G(u, t)`` the reference's constructor takes, so the same problem description runs through the host
+    path (for comparison) and the device path."""
+
+    def __init__(self, G, mods=()):
+        self.G = np.asarray(G, dtype=np.float64)
+        self.mods = [(str(k), float(w), np.asarray(Hc, dtype=np.float64)) for k, w, Hc in mods]
+        for k, _, Hc in self.mods:
+            if k not in ("cos", "sin") or Hc.shape != self.G.shape:
+                raise ValueError("modulation terms are (\"cos\" | \"sin\", omega, H) with H shaped like G")
+
+    def __call__(self, u, t):
+        ub = np.concatenate([[1.0], np.asarray(u)])
+        M = np.tensordot(ub, self.G, axes=(0, 0))
+        for k, w, Hc in self.mods:
+            M = M + (np.cos(w * t) if k == "cos" else np.sin(w * t)) * np.tensordot(ub, Hc, axes=(0, 0))
+        return M
+
+
 class TimeDependentBilinearIntegrator(HostIntegrator):
     """TimeDependentBilinearIntegrator(G, x, u, t, traj; spline_order=1) --
     src/integrators/time_dependent_bilinear_integrator.jl:60-140: defect x_{k+1} - Phi_k x_k for
     dx/dtau = dt_k G(u(tau), t_k + tau dt_k) x on tau in [0, 1], controls held (order 0) or linearly interpolated to
     u_{k+1} (order 1).  ``G(u, t)`` is an arbitrary closure, so this integrator is host-evaluated and merged.  Where the
     reference integrates with adaptive Tsit5 (default tolerances) and differentiates through the solver, this mirror
-    uses fixed-step RK4 (``substeps`` per interval; an analytic map, so complex-step derivatives are exact for it)."""
+    uses fixed-step RK4 (``substeps`` per interval; an analytic map, so complex-step derivatives are exact for it).
 
-    def __init__(self, G, x, u, t, traj, spline_order=1, substeps=32):
+    With ``G`` a ``ModulatedGenerators`` (and ``on_device`` left on) the engine integrates on the GPU -- the same RK4 scheme
+    with its exact first and second derivatives (csrc/dto_tdb.hip) -- and nothing of this class's arithmetic runs."""
+
+    def __init__(self, G, x, u, t, traj, spline_order=1, substeps=32, on_device=True):
         if spline_order not in (0, 1):
             raise ValueError(f"Unsupported spline order: {spline_order}")
+        self.family = G if (on_device and isinstance(G, ModulatedGenerators)) else None
+        self.x_off, self.u_off, self.t_off = traj.components[x][0], traj.components[u][0], traj.components[t][0]
         self.G, self.spline_order, self.substeps = G, int(spline_order), int(substeps)
         self.x_name, self.u_name, self.t_name = x, u, t
         self.u_dim = traj.dims[u]

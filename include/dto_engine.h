@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 4
+#define DTO_ABI_VERSION 5
 
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
@@ -45,6 +45,18 @@ extern "C" {
                                        on the HOST by the reference's own code, merged by the engine.  Structure is
                                        the generic one (dense x_dim x 2z block per interval, _integrators.jl:49-77);
                                        only x_dim is read from the descriptor */
+
+#define DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR 4 /* TimeDependentBilinearIntegrator (time_dependent_bilinear_integrator.jl:
+                                       60-244) for the parametrised generator family
+                                         G(u, t) = sum_{j=0..m} ubar_j ( G_j + sum_c phi_c(t) H_cj ),  ubar_0 = 1,
+                                         phi_c(t) = cos(omega_c t) or sin(omega_c t)
+                                       (carrier-modulated drives, rotating-frame terms; the reference's own test
+                                       G(a) + 0.1 cos(t) I is the case H_c0 = 0.1 I).  Evaluated ON THE DEVICE: defect
+                                       x_{k+1} - Phi_k x_k of  dx/dtau = dt_k G(u(tau), t_k + tau dt_k) x,  tau in [0,1], by
+                                       classical RK4 with `substeps` fixed steps (the reference integrates adaptively with
+                                       Tsit5), controls held (spline_order 0) or interpolated linearly to u_{k+1} (1), with the
+                                       exact first and second derivatives of that discrete map.  An arbitrary closure G(u, t)
+                                       stays DTO_INTEGRATOR_EXTERNAL */
 
 /* objective term kinds (src/objectives/) */
 #define DTO_OBJECTIVE_QUADRATIC_REGULARIZER 1 /* regularizers.jl:38-167   */
@@ -90,6 +102,14 @@ typedef struct dto_integrator_desc {
     int32_t u_dim;  /* bilinear: number of drives m; derivative: ignored (= x_dim) */
     const double* G; /* bilinear: (m+1) matrices x_dim*x_dim, column-major, G[0] = G(0) (drift),
                         G[j] = G(e_j) - G(0) (drive j); copied at create.  NULL for derivative. */
+    /* DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR only (zero / NULL otherwise) */
+    int32_t t_off;        /* component offset of the time variable t inside a knot (0-based) */
+    int32_t spline_order; /* 0: controls held over the interval, 1: linearly interpolated to u_{k+1} */
+    int32_t substeps;     /* fixed RK4 steps per interval */
+    int32_t n_mod;        /* number of modulation terms c */
+    const int32_t* mod_kind; /* [n_mod] 1 = cos(omega t), 2 = sin(omega t) */
+    const double* mod_omega; /* [n_mod] */
+    const double* H;         /* [n_mod][(m+1)] matrices x_dim*x_dim, column-major; copied at create */
 } dto_integrator_desc;
 
 typedef struct dto_objective_desc {

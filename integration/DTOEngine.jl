@@ -1,4 +1,4 @@
-# DTOEngine.jl -- the reference-side binding of libdto_engine.so (include/dto_engine.h, ABI version 4).
+# DTOEngine.jl -- the reference-side binding of libdto_engine.so (include/dto_engine.h, ABI version 5).
 #
 # Drop this file into DirectTrajOpt.jl (e.g. src/solvers/DTOEngine.jl, `include`d from src/solvers/_solvers.jl) and
 # replace the evaluator at the two swap points:
@@ -32,7 +32,7 @@ using ..Constraints: AbstractNonlinearConstraint, NonlinearKnotPointConstraint
 using ..CommonInterface: evaluate!, eval_jacobian, eval_hessian_of_lagrangian
 
 const lib = get(ENV, "DTO_ENGINE_LIB", "libdto_engine.so")
-const DTO_ABI_VERSION = Int32(4)
+const DTO_ABI_VERSION = Int32(5)
 
 const DTO_INTEGRATOR_BILINEAR = Int32(1)
 const DTO_INTEGRATOR_DERIVATIVE = Int32(2)
@@ -51,7 +51,18 @@ struct IntegratorDesc
     u_off::Int32
     u_dim::Int32
     G::Ptr{Float64}
+    t_off::Int32
+    spline_order::Int32
+    substeps::Int32
+    n_mod::Int32
+    mod_kind::Ptr{Int32}
+    mod_omega::Ptr{Float64}
+    H::Ptr{Float64}
 end
+# bilinear / derivative / host-evaluated integrators leave the time-dependent fields empty
+IntegratorDesc(kind, x_off, x_dim, u_off, u_dim, G) =
+    IntegratorDesc(kind, x_off, x_dim, u_off, u_dim, G, Int32(0), Int32(0), Int32(0), Int32(0), Ptr{Int32}(C_NULL),
+                   Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL))
 
 struct ObjectiveDesc
     kind::Int32

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(engine_lib):
 
 def test_struct_sizes_match_header_layout():
     # sizes computed by hand from include/dto_engine.h (LP64): catches field drift between C and ctypes
-    assert ctypes.sizeof(dto_amd.capi.IntegratorDesc) == 32
+    assert ctypes.sizeof(dto_amd.capi.IntegratorDesc) == 72
     assert ctypes.sizeof(dto_amd.capi.ObjectiveDesc) == 112
     assert ctypes.sizeof(dto_amd.capi.ConstraintDesc) == 64
     assert ctypes.sizeof(dto_amd.capi.ProblemDesc) == 96
