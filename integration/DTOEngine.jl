@@ -37,6 +37,7 @@ const DTO_ABI_VERSION = Int32(5)
 const DTO_INTEGRATOR_BILINEAR = Int32(1)
 const DTO_INTEGRATOR_DERIVATIVE = Int32(2)
 const DTO_INTEGRATOR_EXTERNAL = Int32(3)
+const DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR = Int32(4)
 const DTO_OBJECTIVE_QUADRATIC_REGULARIZER = Int32(1)
 const DTO_OBJECTIVE_LINEAR_REGULARIZER = Int32(2)
 const DTO_OBJECTIVE_MINIMUM_TIME = Int32(3)
@@ -124,6 +125,43 @@ struct ExternalValues
     second::Ptr{Float64}
 end
 
+# ---- TimeDependentBilinearIntegrator on the device ------------------------------------------------------------------
+"""
+The generator family the engine integrates on the GPU (DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR):
+
+    G(u, t) = sum_{j=0..m} ubar_j ( G[:, :, j+1] + sum_c phi_c(t) H[:, :, j+1, c] ),  ubar_0 = 1,  phi_c = cos | sin (omegas[c] t)
+
+The object is callable, so it is also the `G` the reference's constructor takes:
+
+    fam = DTOEngine.ModulatedGenerators(G, Int32[1], [1.7], H; substeps = 32)
+    B = TimeDependentBilinearIntegrator(fam, :x, :u, :t, traj; spline_order = 1)
+    DTOEngine.device_family!(B, fam)        # tells the evaluator to run B on the device
+
+(`G` is captured inside the ODE problem the integrator builds, out of reach of the struct's fields, hence the registration.)
+The engine integrates with classical RK4, `substeps` fixed steps per interval, and returns the exact derivatives of that
+scheme; the reference integrates adaptively (Tsit5).  Any other closure keeps running in Julia and is merged.
+"""
+struct ModulatedGenerators
+    G::Array{Float64,3}
+    kinds::Vector{Int32}      # 1 = cos, 2 = sin
+    omegas::Vector{Float64}
+    H::Array{Float64,4}       # n x n x (m+1) x n_mod
+    substeps::Int
+end
+ModulatedGenerators(G, kinds, omegas, H; substeps::Int = 32) =
+    ModulatedGenerators(Array{Float64,3}(G), Vector{Int32}(kinds), Vector{Float64}(omegas), Array{Float64,4}(H), substeps)
+function (g::ModulatedGenerators)(u, t)
+    ub = vcat(1.0, u)
+    M = sum(ub[j] .* g.G[:, :, j] for j in eachindex(ub))
+    for c in eachindex(g.omegas)
+        phi = g.kinds[c] == 1 ? cos(g.omegas[c] * t) : sin(g.omegas[c] * t)
+        M = M .+ phi .* sum(ub[j] .* g.H[:, :, j, c] for j in eachindex(ub))
+    end
+    return M
+end
+const DEVICE_FAMILIES = IdDict{Any,ModulatedGenerators}()
+device_family!(B, fam::ModulatedGenerators) = (DEVICE_FAMILIES[B] = fam; B)
+
 # ---- the evaluator --------------------------------------------------------------------------------------------------
 mutable struct GPUEvaluator <: MOI.AbstractNLPEvaluator
     handle::Ptr{Cvoid}
@@ -197,7 +235,14 @@ function GPUEvaluator(prob::DirectTrajOptProblem; eval_hessian::Bool = true, dev
         elseif integ isa DerivativeIntegrator
             push!(idescs, IntegratorDesc(DTO_INTEGRATOR_DERIVATIVE, first0(traj, integ.x_name), Int32(integ.x_dim),
                                          first0(traj, integ.ẋ_name), Int32(integ.x_dim), Ptr{Float64}(C_NULL)))
-        else   # TimeDependentBilinearIntegrator, user integrators: evaluated here, merged by the engine
+        elseif haskey(DEVICE_FAMILIES, integ)   # TimeDependentBilinearIntegrator with a registered generator family
+            fam = DEVICE_FAMILIES[integ]
+            push!(keep, fam)
+            push!(idescs, IntegratorDesc(DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR, first0(traj, integ.x_name), Int32(integ.x_dim),
+                                         first0(traj, integ.u_name), Int32(integ.u_dim), pointer(fam.G),
+                                         first0(traj, integ.t_name), Int32(integ.spline_order), Int32(fam.substeps),
+                                         Int32(length(fam.omegas)), pointer(fam.kinds), pointer(fam.omegas), pointer(fam.H)))
+        else   # TimeDependentBilinearIntegrator with an arbitrary closure, user integrators: evaluated here, merged by the engine
             push!(idescs, IntegratorDesc(DTO_INTEGRATOR_EXTERNAL, Int32(0), Int32(integ.x_dim), Int32(0), Int32(0), Ptr{Float64}(C_NULL)))
             push!(ext_integrators, (integ, row))
         end
