@@ -8,7 +8,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 
 all: $(LIB)
 
-$(CSRC)/dto_kernels.o: $(CSRC)/dto_kernels.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h
+$(CSRC)/dto_kernels.o: $(CSRC)/dto_kernels.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h $(CSRC)/dto_hostxfer.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/dto_small.o: $(CSRC)/dto_small.hip $(CSRC)/dto_kernels.h
@@ -20,11 +20,14 @@ $(CSRC)/dto_tdb.o: $(CSRC)/dto_tdb.hip $(CSRC)/dto_kernels.h
 $(CSRC)/dto_sweep_fused.o: $(CSRC)/dto_sweep_fused.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/dto_engine.o: $(CSRC)/dto_engine.cpp $(CSRC)/dto_kernels.h include/dto_engine.h
+$(CSRC)/dto_hostxfer.o: $(CSRC)/dto_hostxfer.cpp $(CSRC)/dto_hostxfer.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_small.o $(CSRC)/dto_sweep_fused.o $(CSRC)/dto_tdb.o $(CSRC)/dto_engine.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+$(CSRC)/dto_engine.o: $(CSRC)/dto_engine.cpp $(CSRC)/dto_kernels.h $(CSRC)/dto_hostxfer.h include/dto_engine.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_small.o $(CSRC)/dto_sweep_fused.o $(CSRC)/dto_tdb.o $(CSRC)/dto_hostxfer.o $(CSRC)/dto_engine.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
 clean:
 	rm -f $(CSRC)/*.o $(LIB)

@@ -19,7 +19,10 @@
 #include <string>
 #include <vector>
 
+#include "dto_hostxfer.h"
 #include "dto_kernels.h"
+
+#include <memory>
 
 using namespace dto;
 
@@ -158,6 +161,18 @@ struct dto_handle {
     std::vector<int64_t> integ_row_off;
     std::vector<ConHost> con;
     std::vector<KObj> obj;
+    struct ObjInfo {  // host copy of what a built-in objective term touches in the Hessian (the D2H plan needs it)
+        int kind, comp_off, comp_dim;
+        std::vector<int32_t> comps;
+        std::vector<int64_t> times;  // owned, 0-based
+    };
+    std::vector<ObjInfo> obj_info;
+    // host-pointer entry points: only the entries that can change cross PCIe (dto_hostxfer.h); built lazily at the first
+    // host-pointer Jacobian / Hessian call, option "host_xfer" = 0 keeps the plain whole-slab copy
+    std::unique_ptr<HostXfer> xfer;
+    XferPlan jac_plan, hess_plan;
+    bool plans_built = false;
+    int host_xfer = 1;
     std::vector<ExtObjHost> ext_obj;
     std::vector<KExtInt> ext_int;  // DTO_INTEGRATOR_EXTERNAL, slot = index
     std::vector<TdbHost> tdb;      // DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR
@@ -1106,6 +1121,170 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// host-pointer hand-off plans (dto_hostxfer.h): which slab entries a callback may write a call-dependent value to
+// ------------------------------------------------------------------------------------------
+void build_jac_plan(dto_handle* h) {
+    XferPlan& p = h->jac_plan;
+    const KProb& P = h->P;
+    const int z = h->z;
+    p.total = h->info.jac_len;
+    auto var = [&](int64_t at, int64_t n) { if (n > 0) { p.start.push_back(at); p.len.push_back(n); } };
+    auto one = [&](int64_t at, double v) { p.one_pos.push_back(at); p.one_val.push_back(v); };
+    for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) {
+        const int has_prev = kn >= 1, has_own = kn < h->K;
+        const int cnt = has_prev + has_own;
+        for (int j = 0; j < z; ++j) {
+            const int64_t c = kn * z + j;
+            const int64_t base = h->colptr[c] - P.jac_lo;
+            int pre = 0;
+            for (size_t i = 0; i < h->integ_kind.size(); ++i) {
+                const int d = h->integ_dim[i];
+                const int64_t prev_at = base + (int64_t)pre * cnt, own_at = prev_at + (has_prev ? d : 0);
+                const int kind = h->integ_kind[i];
+                if (kind == DTO_INTEGRATOR_BILINEAR) {
+                    const KBil& b = h->bil[h->integ_index[i]].k;
+                    const bool xcol = j >= b.x_off && j < b.x_off + b.n;
+                    // z_{k+1} half: identity on the state columns, zeros elsewhere -- constant
+                    if (has_prev && xcol) one(prev_at + (j - b.x_off), 1.0);
+                    // own rows: -E_k (x), the tangents (u) and -G(u) E_k x (dt) change; every other column is a structural zero
+                    if (has_own && (xcol || (j >= b.u_off && j < b.u_off + b.m) || j == h->dt_idx)) var(own_at, d);
+                } else if (kind == DTO_INTEGRATOR_DERIVATIVE) {
+                    const KDer& dd = h->der[h->integ_index[i]];
+                    const bool xcol = j >= dd.x_off && j < dd.x_off + dd.d, xdcol = j >= dd.xdot_off && j < dd.xdot_off + dd.d;
+                    if (has_prev && xcol) one(prev_at + (j - dd.x_off), 1.0);
+                    if (has_own) {
+                        if (xdcol || j == h->dt_idx) var(own_at, d);         // -dt I and -xdot
+                        else if (xcol) one(own_at + (j - dd.x_off), -1.0);   // -I (a column that is x AND xdot / dt is variable)
+                    }
+                } else {  // host-evaluated and time-dependent bilinear integrators: dense blocks, both halves
+                    if (has_prev) var(prev_at, d);
+                    if (has_own) var(own_at, d);
+                }
+                pre += d;
+            }
+            var(base + (int64_t)h->D * cnt, h->colptr[c + 1] - h->colptr[c] - (int64_t)h->D * cnt);  // constraint entries
+        }
+    }
+    if (h->k_hi == h->N) {  // global-variable columns ride with the last knot: constraint entries only
+        const int64_t c0 = h->N * z;
+        var(h->colptr[c0] - P.jac_lo, h->colptr[h->n_vars] - h->colptr[c0]);
+    }
+    // the builders above emit per column in ascending order, but a derivative integrator's -1 may precede a later one's runs
+    std::vector<size_t> idx(p.one_pos.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return p.one_pos[a] < p.one_pos[b]; });
+    std::vector<int64_t> op(idx.size());
+    std::vector<double> ov(idx.size());
+    for (size_t i = 0; i < idx.size(); ++i) { op[i] = p.one_pos[idx[i]]; ov[i] = p.one_val[idx[i]]; }
+    p.one_pos.swap(op);
+    p.one_val.swap(ov);
+}
+
+void build_hess_plan(dto_handle* h) {
+    XferPlan& p = h->hess_plan;
+    const KProb& P = h->P;
+    const int z = h->z;
+    p.total = h->info.hess_len;
+    const bool dense_blocks = !h->ext_int.empty() || !h->tdb.empty();  // their 2z x 2z blocks touch everything
+    // listed times of the knot terms, per owned knot
+    std::vector<std::vector<std::pair<int, int>>> extra((size_t)P.n_knots);  // (a <= b) pairs per local knot
+    auto add_pairs = [&](int64_t kn, const std::vector<int32_t>& comps) {
+        if (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots) return;
+        auto& e = extra[(size_t)(kn - P.kn_lo)];
+        for (int a : comps)
+            for (int b : comps) e.emplace_back(std::min(a, b), std::max(a, b));
+    };
+    for (auto& oi : h->obj_info) {
+        for (int64_t kn : oi.times) {
+            auto& e = extra[(size_t)(kn - P.kn_lo)];
+            if (oi.kind == DTO_OBJECTIVE_QUADRATIC_REGULARIZER) {
+                for (int c = 0; c < oi.comp_dim; ++c) {
+                    const int a = oi.comp_off + c;
+                    e.emplace_back(a, a);
+                    if (a < h->dt_idx) e.emplace_back(a, h->dt_idx);
+                }
+                e.emplace_back(h->dt_idx, h->dt_idx);
+            } else if (oi.kind == DTO_OBJECTIVE_LINEAR_REGULARIZER) {
+                for (int c = 0; c < oi.comp_dim; ++c)
+                    if (oi.comp_off + c <= h->dt_idx) e.emplace_back(oi.comp_off + c, h->dt_idx);
+            } else if (oi.kind == DTO_OBJECTIVE_KNOT_SQDIST) {
+                for (int a : oi.comps) e.emplace_back(a, a);
+            } else if (oi.kind == DTO_OBJECTIVE_KNOT_LOWRANK_INFIDELITY) {
+                add_pairs(kn, oi.comps);
+            }
+        }
+    }
+    for (auto& e : h->ext_obj)
+        for (int64_t kn : e.times0) add_pairs(kn, e.comps);
+    for (auto& c : h->con)
+        if (!c.global)
+            for (int64_t kn : c.times0) add_pairs(kn, c.comps);
+    const int64_t tri = (int64_t)z * (z + 1) / 2;
+    std::vector<uint8_t> mask((size_t)z * z);
+    auto var = [&](int64_t at, int64_t n) { if (n > 0) { p.start.push_back(at); p.len.push_back(n); } };
+    for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) {
+        std::fill(mask.begin(), mask.end(), dense_blocks ? 1 : 0);
+        auto set = [&](int a, int b) { mask[(size_t)std::min(a, b) + (size_t)z * std::max(a, b)] = 1; };
+        if (!dense_blocks) {
+            if (kn < h->K) {
+                for (auto& bh : h->bil) {
+                    const KBil& b = bh.k;
+                    for (int i = 0; i < b.n; ++i) {
+                        for (int j = 0; j < b.m; ++j) set(b.x_off + i, b.u_off + j);
+                        set(b.x_off + i, h->dt_idx);
+                    }
+                    for (int i = 0; i < b.m; ++i) {
+                        for (int j = 0; j < b.m; ++j) set(b.u_off + i, b.u_off + j);
+                        set(b.u_off + i, h->dt_idx);
+                    }
+                    set(h->dt_idx, h->dt_idx);
+                }
+                for (auto& dd : h->der)
+                    for (int i = 0; i < dd.d; ++i) set(dd.xdot_off + i, h->dt_idx);
+            }
+            for (auto& ab : extra[(size_t)(kn - P.kn_lo)]) set(ab.first, ab.second);
+        }
+        const int64_t blk0 = hess_block_start(h, kn) - P.hess_lo;
+        for (int b = 0; b < z; ++b) {
+            int64_t col = blk0 + (kn == 0 ? (int64_t)b * (b + 1) / 2 : (int64_t)b * z + (int64_t)b * (b + 1) / 2);
+            if (kn >= 1) {
+                if (dense_blocks) var(col, z);  // off-diagonal block (kn-1, kn): the cross part of interval kn-1
+                col += z;
+            }
+            int a = 0;
+            while (a <= b) {
+                while (a <= b && !mask[(size_t)a + (size_t)z * b]) ++a;
+                const int a0 = a;
+                while (a <= b && mask[(size_t)a + (size_t)z * b]) ++a;
+                var(col + a0, a - a0);
+            }
+        }
+        (void)tri;
+    }
+    if (h->k_hi == h->N) var(h->hess_block_nnz - P.hess_lo, (int64_t)h->tail_rows.size());  // global-column tail
+}
+
+void ensure_plans(dto_handle* h) {
+    if (h->plans_built) return;
+    h->plans_built = true;
+    if (!h->host_xfer) return;
+    build_jac_plan(h);
+    if (h->eval_hessian) build_hess_plan(h);
+    for (XferPlan* p : {&h->jac_plan, &h->hess_plan}) {
+        if (p->total <= 0) continue;
+        p->finalize(HostXfer::CHUNK_DOUBLES);
+        // shipping the runs pays only when a good part of the slab stays at home
+        if (p->packed_total() * 10 > p->total * 9) { p->poff.clear(); continue; }
+        p->d_start = own(h, dupload(p->start));
+        p->d_len = own(h, dupload(p->len));
+        p->d_poff = own(h, dupload(p->poff));
+        p->d_packed = own(h, dalloc<double>((size_t)std::max<int64_t>(p->packed_total(), 1)));
+    }
+    if (h->jac_plan.usable() || h->hess_plan.usable()) h->xfer.reset(new HostXfer());
+}
+
 double* staging(dto_handle* h, size_t n) {
     if (n > h->d_out_cap) {
         h->d_out = own(h, dalloc<double>(n));
@@ -1607,6 +1786,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             o.n_times = (int64_t)times.size();
             o.times = own(h, dupload(times));
             h->obj.push_back(o);
+            dto_handle::ObjInfo oi;
+            oi.kind = s.kind; oi.comp_off = s.comp_off; oi.comp_dim = s.comp_dim; oi.times = times;
+            if (s.comps && s.n_comps > 0) oi.comps.assign(s.comps, s.comps + s.n_comps);
+            h->obj_info.push_back(std::move(oi));
         }
 
         // host-evaluated objective terms: which listings this handle places (knot part: the knot's owner; entries in
@@ -1919,6 +2102,19 @@ int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals) {
     return guarded(h, [&] {
         upload_Z(h, Z);
         double* o = staging(h, (size_t)h->info.jac_len);
+        ensure_plans(h);
+        if (h->jac_plan.usable()) {
+            // constants are filled by host threads while the GPU computes; only the variable runs cross PCIe
+            h->xfer->fill_constants_async(h->jac_plan, vals);
+            try {
+                do_jacobian(h, h->d_Z, o, h->stream);
+                h->xfer->fetch(h->jac_plan, o, vals, h->stream);
+            } catch (...) {
+                h->xfer->fetch(XferPlan{}, o, vals, h->stream);  // joins the host threads before the error leaves
+                throw;
+            }
+            return;
+        }
         do_jacobian(h, h->d_Z, o, h->stream);
         HIP_CHECK(hipMemcpyAsync(vals, o, sizeof(double) * (size_t)h->info.jac_len, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1930,6 +2126,18 @@ int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double*
         upload_Z(h, Z);
         HIP_CHECK(hipMemcpyAsync(h->d_mu, mu, sizeof(double) * (size_t)h->n_cons, hipMemcpyHostToDevice, h->stream));
         double* o = staging(h, (size_t)h->info.hess_len);
+        ensure_plans(h);
+        if (h->hess_plan.usable()) {
+            h->xfer->fill_constants_async(h->hess_plan, vals);
+            try {
+                do_hessian(h, h->d_Z, sigma, h->d_mu, o, h->stream);
+                h->xfer->fetch(h->hess_plan, o, vals, h->stream);
+            } catch (...) {
+                h->xfer->fetch(XferPlan{}, o, vals, h->stream);
+                throw;
+            }
+            return;
+        }
         do_hessian(h, h->d_Z, sigma, h->d_mu, o, h->stream);
         HIP_CHECK(hipMemcpyAsync(vals, o, sizeof(double) * (size_t)h->info.hess_len, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -2030,6 +2238,11 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(h, "dto_set_option: sweep_form takes 0 (fused where it applies) or 1 (step per launch)");
         h->sweep_form = (int)value;
         drop_caches(h);
+        return 0;
+    }
+    if (std::string(name) == "host_xfer") {
+        if (h->plans_built) return fail(h, "dto_set_option: host_xfer must be set before the first host-pointer Jacobian / Hessian call");
+        h->host_xfer = value != 0;
         return 0;
     }
     if (std::string(name) == "chain_chunk") {

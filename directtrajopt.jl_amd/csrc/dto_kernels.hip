@@ -18,6 +18,7 @@
 //       one step for all knots is a single GEMM  [G_0 .. G_m] x (columns of all knots)  (k_sweep).
 #include "dto_gemm.hip.h"
 #include "dto_kernels.h"
+#include "dto_hostxfer.h"
 
 #include <cstdlib>
 
@@ -79,6 +80,25 @@ void launch_bits_equal(hipStream_t st, const double* a, const double* b, int64_t
     hipLaunchKernelGGL(k_bits_equal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        reinterpret_cast<const unsigned long long*>(a), reinterpret_cast<const unsigned long long*>(b), n, flag);
 }
+// packed[poff[r] + i] = slab[start[r] + i]: the variable runs of a value slab, back to back (dto_hostxfer.h).  One
+// wavefront per run (a run is typically one 256-entry column of -E_k or a handful of entries).
+__global__ void __launch_bounds__(256) k_pack_runs(const double* __restrict__ slab, const int64_t* __restrict__ start,
+                                                   const int64_t* __restrict__ len, const int64_t* __restrict__ poff, int64_t n_runs,
+                                                   double* __restrict__ packed) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_runs) return;
+    const int lane = threadIdx.x & 63;
+    const double* src = slab + start[r];
+    double* dst = packed + poff[r];
+    const int64_t n = len[r];
+    for (int64_t i = lane; i < n; i += 64) dst[i] = __builtin_nontemporal_load(&src[i]);
+}
+void launch_pack_runs(hipStream_t st, const double* slab, const int64_t* start, const int64_t* len, const int64_t* poff,
+                      int64_t n_runs, double* packed) {
+    if (n_runs <= 0) return;
+    hipLaunchKernelGGL(k_pack_runs, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, st, slab, start, len, poff, n_runs, packed);
+}
+
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n) {
     if (n <= 0) return;
     int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

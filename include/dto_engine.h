@@ -266,7 +266,13 @@ int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const do
 /*   "expm_form" (default 0): evaluation form of the matrix-exponential polynomial in eval_constraint_jacobian.  0 picks per
  *   call by cost: two products for the degree-16 Taylor polynomial (backward-error radius 0.78) or three products for an
  *   order-26 approximant (radius 2.82, i.e. up to two squarings fewer); 2 / 3 force one form (tests, measurements). */
-/*   "chain_chunk" (default 0 = the engine's workspace budget): at most this many intervals per chunk of the propagator
+/*   "host_xfer" (default 1): the host-pointer dto_eval_jacobian / dto_eval_hessian copy only the entries that can change
+ *   from call to call (about half of a Jacobian slab, ~1 % of a Hessian slab) through a pinned ring and fill the constant
+ *   entries (identity / zero runs) with host threads while the GPU computes; 0 copies the whole slab in one piece.  To be set
+ *   before the first such call.
+ *   "sweep_form" (default 0): 0 runs the generator sweep as one persistent launch where that form applies, 1 always one
+ *   launch per Taylor step.
+ *   "chain_chunk" (default 0 = the engine's workspace budget): at most this many intervals per chunk of the propagator
  *   chain (what a 16000-knot trajectory does by itself; tests use it to exercise the chunk loop on small problems).
  *   "debug_bad_launch" (default 0): tests of the error convention -- 1 gives the next callbacks' kernels an invalid launch
  *   configuration, which must come back as a non-zero return code with text. */

@@ -300,3 +300,39 @@ def test_reuse_forward_sweep_between_callbacks():
         assert rel_err(out, want[id(Z1)]["g"]) <= 1e-13
     finally:
         ref.close(); ev.close()
+
+
+def test_host_pointer_hand_off_ships_only_what_changes():
+    """dto_hostxfer: the host-pointer Jacobian / Hessian copy the variable runs only and fill constants on the host.  The
+    result must be bit-identical to the whole-slab copy (option host_xfer = 0), into buffers pre-filled with garbage, for
+    problems with every kind of term (constraints, closures, foreign integrators, globals, several bilinear integrators)."""
+    import dto_amd
+    cases = [(O.make_scaled_problem(9, 24, 3, seed=2, with_constraint=True), "numeric"), (O.make_standard_problem(N=8), "numeric"),
+             (O.make_closure_problem(), "analytic"), (O.make_external_integrator_problem(), "analytic"),
+             (O.make_global_problem(), "analytic"), (O.make_type1_derivative_problem(), "numeric"), (O.make_ket_problem(), "numeric")]
+    for p, how in cases:
+        outs = []
+        for on in (1, 0):
+            ev = dto_amd.Evaluator(to_engine(p, how))
+            ev.set_option("host_xfer", on)
+            mu = np.random.default_rng(3).standard_normal(ev.n_constraints)
+            Z = p.Z0 + 0.01
+            for rep in range(2):  # the second call re-uses the ring and the plans
+                j = np.full(ev.shard.jac_len, np.nan); ev.eval_constraint_jacobian(j, Z)
+                h = np.full(ev.shard.hess_len, 1e300); ev.eval_hessian_lagrangian(h, Z, 0.7, mu)
+            outs.append((j, h))
+            ev.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # shards too
+    p = O.make_scaled_problem(11, 8, 2, seed=3, with_constraint=True)
+    for lo, hi in ((1, 4), (5, 11)):
+        outs = []
+        for on in (1, 0):
+            ev = dto_amd.Evaluator(to_engine(p), k_lo=lo, k_hi=hi)
+            ev.set_option("host_xfer", on)
+            mu = np.random.default_rng(3).standard_normal(ev.n_constraints)
+            j = np.full(ev.shard.jac_len, np.nan); ev.eval_constraint_jacobian(j, p.Z0)
+            h = np.full(ev.shard.hess_len, np.nan); ev.eval_hessian_lagrangian(h, p.Z0, 0.7, mu)
+            outs.append((j, h))
+            ev.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
