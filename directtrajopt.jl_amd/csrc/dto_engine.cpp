@@ -171,6 +171,8 @@ struct dto_handle {
     // host-pointer Jacobian / Hessian call, option "host_xfer" = 0 keeps the plain whole-slab copy
     std::unique_ptr<HostXfer> xfer;
     XferPlan jac_plan, hess_plan;
+    int xfer_cap = 0;                                         // host-pointer Jacobian: chain chunk (intervals) for the early hand-over, 0 = off
+    std::function<void(int64_t, int)> on_chain_chunk;         // ... and its hook: (first local interval, count) of a finished chunk
     bool plans_built = false;
     int host_xfer = 1;
     std::vector<ExtObjHost> ext_obj;
@@ -692,7 +694,8 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     const int64_t nint = h->P.n_int;
     double d2max = 0.0;
     if (nint <= 0) return d2max;
-    const int cap = h->chain_chunk > 0 ? std::min(h->chain_chunk, b.chain_cap) : b.chain_cap;
+    int cap = h->chain_chunk > 0 ? std::min(h->chain_chunk, b.chain_cap) : b.chain_cap;
+    if (h->xfer_cap > 0) cap = std::min(cap, h->xfer_cap);
     int s_ub = 1;
     if (b1max == b1max && b1max > THETA_16) s_ub = std::isinf(b1max) ? 60 : std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
     s_ub = std::min(s_ub, 60);
@@ -784,6 +787,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             launch_bgemm_square(st, npad, nb, w, src, src == 4 ? 5 : 4, it, h->P, b.k, int0, vals);
             src = src == 4 ? 5 : 4;
         }
+        if (h->on_chain_chunk) h->on_chain_chunk(c0, nb);  // the -E_k of these intervals are final behind what is enqueued now
     }
     if (after_last_enqueue) after_last_enqueue(d2max);
     return d2max;
@@ -1130,8 +1134,13 @@ void build_jac_plan(dto_handle* h) {
     const KProb& P = h->P;
     const int z = h->z;
     p.total = h->info.jac_len;
-    auto var = [&](int64_t at, int64_t n) { if (n > 0) { p.start.push_back(at); p.len.push_back(n); } };
+    auto var = [&](int64_t at, int64_t n, int64_t early = -1) {
+        if (n > 0) { p.start.push_back(at); p.len.push_back(n); p.early.push_back((int32_t)early); }
+    };
     auto one = [&](int64_t at, double v) { p.one_pos.push_back(at); p.one_val.push_back(v); };
+    // the -E_k block of a lone general-path bilinear integrator is written by the propagator chain alone (do_jacobian): final
+    // with its chain chunk
+    const bool lone = h->bil.size() == 1 && P.n_int > 0 && !h->bil[0].small;
     for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) {
         const int has_prev = kn >= 1, has_own = kn < h->K;
         const int cnt = has_prev + has_own;
@@ -1149,7 +1158,8 @@ void build_jac_plan(dto_handle* h) {
                     // z_{k+1} half: identity on the state columns, zeros elsewhere -- constant
                     if (has_prev && xcol) one(prev_at + (j - b.x_off), 1.0);
                     // own rows: -E_k (x), the tangents (u) and -G(u) E_k x (dt) change; every other column is a structural zero
-                    if (has_own && (xcol || (j >= b.u_off && j < b.u_off + b.m) || j == h->dt_idx)) var(own_at, d);
+                    if (has_own && (xcol || (j >= b.u_off && j < b.u_off + b.m) || j == h->dt_idx))
+                        var(own_at, d, lone && xcol && j != h->dt_idx && kn - P.kn_lo < P.n_int ? kn - P.kn_lo : -1);
                 } else if (kind == DTO_INTEGRATOR_DERIVATIVE) {
                     const KDer& dd = h->der[h->integ_index[i]];
                     const bool xcol = j >= dd.x_off && j < dd.x_off + dd.d, xdcol = j >= dd.xdot_off && j < dd.xdot_off + dd.d;
@@ -1274,12 +1284,12 @@ void ensure_plans(dto_handle* h) {
     if (h->eval_hessian) build_hess_plan(h);
     for (XferPlan* p : {&h->jac_plan, &h->hess_plan}) {
         if (p->total <= 0) continue;
-        p->finalize(HostXfer::CHUNK_DOUBLES);
+        p->finalize(h->P.n_int, HostXfer::CHUNK_DOUBLES);
         // shipping the runs pays only when a good part of the slab stays at home
-        if (p->packed_total() * 10 > p->total * 9) { p->poff.clear(); continue; }
-        p->d_start = own(h, dupload(p->start));
-        p->d_len = own(h, dupload(p->len));
-        p->d_poff = own(h, dupload(p->poff));
+        if (p->packed_total() * 10 > p->total * 9 || p->n_runs() == 0) continue;
+        p->d_start = own(h, dupload(p->pk_start));
+        p->d_len = own(h, dupload(p->pk_len));
+        p->d_poff = own(h, dupload(p->pk_poff));
         p->d_packed = own(h, dalloc<double>((size_t)std::max<int64_t>(p->packed_total(), 1)));
     }
     if (h->jac_plan.usable() || h->hess_plan.usable()) h->xfer.reset(new HostXfer());
@@ -2104,13 +2114,28 @@ int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals) {
         double* o = staging(h, (size_t)h->info.jac_len);
         ensure_plans(h);
         if (h->jac_plan.usable()) {
-            // constants are filled by host threads while the GPU computes; only the variable runs cross PCIe
-            h->xfer->fill_constants_async(h->jac_plan, vals);
+            // constants are filled by host threads while the GPU computes; only the variable runs cross PCIe, and the -E_k
+            // blocks start crossing as soon as their chain chunk is done (dto_hostxfer.h)
+            const XferPlan& pl = h->jac_plan;
+            struct Reset {
+                dto_handle* h;
+                ~Reset() { h->xfer_cap = 0; h->on_chain_chunk = nullptr; }
+            } reset{h};
+            h->xfer->begin(pl, o, vals);
             try {
+                if (pl.n_early() > 0) {
+                    static const int chunks = std::max(1, tune_int("DTO_XFER_CHUNKS", 4));
+                    const int64_t nint = h->P.n_int;
+                    if (nint >= 512 && chunks > 1) h->xfer_cap = (int)(((nint + chunks - 1) / chunks + 7) / 8 * 8);
+                    h->on_chain_chunk = [&](int64_t c0, int nb) {
+                        h->xfer->submit(pl.early_off[(size_t)c0], pl.early_off[(size_t)(c0 + nb)], h->stream);
+                    };
+                }
                 do_jacobian(h, h->d_Z, o, h->stream);
-                h->xfer->fetch(h->jac_plan, o, vals, h->stream);
+                h->xfer->submit(pl.n_early(), pl.n_runs(), h->stream);
+                h->xfer->finish();
             } catch (...) {
-                h->xfer->fetch(XferPlan{}, o, vals, h->stream);  // joins the host threads before the error leaves
+                h->xfer->abort();  // joins the host threads before the error leaves
                 throw;
             }
             return;
@@ -2128,12 +2153,14 @@ int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double*
         double* o = staging(h, (size_t)h->info.hess_len);
         ensure_plans(h);
         if (h->hess_plan.usable()) {
-            h->xfer->fill_constants_async(h->hess_plan, vals);
+            const XferPlan& pl = h->hess_plan;
+            h->xfer->begin(pl, o, vals);
             try {
                 do_hessian(h, h->d_Z, sigma, h->d_mu, o, h->stream);
-                h->xfer->fetch(h->hess_plan, o, vals, h->stream);
+                h->xfer->submit(0, pl.n_runs(), h->stream);
+                h->xfer->finish();
             } catch (...) {
-                h->xfer->fetch(XferPlan{}, o, vals, h->stream);
+                h->xfer->abort();
                 throw;
             }
             return;

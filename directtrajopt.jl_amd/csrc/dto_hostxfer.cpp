@@ -15,35 +15,55 @@ void hip_check(hipError_t e, const char* what) {
 }
 }  // namespace
 
-void XferPlan::finalize(int64_t chunk_doubles) {
-    // merge runs that touch (the builders emit them per column / per term)
+void XferPlan::finalize(int64_t n_int, int64_t max_run) {
+    const bool has_early = !early.empty();
+    // merge runs that touch (the builders emit them per column / per term) when they belong to the same class; cut a run
+    // that would not fit a ring slot
     std::vector<int64_t> s2, l2;
+    std::vector<int32_t> e2;
     for (size_t i = 0; i < start.size(); ++i) {
         if (len[i] <= 0) continue;
-        if (!s2.empty() && s2.back() + l2.back() >= start[i]) {
+        const int32_t cls = has_early ? early[i] : -1;
+        if (!s2.empty() && s2.back() + l2.back() >= start[i] && e2.back() == cls) {
             const int64_t end = std::max(s2.back() + l2.back(), start[i] + len[i]);
             l2.back() = end - s2.back();
         } else {
             s2.push_back(start[i]);
             l2.push_back(len[i]);
+            e2.push_back(cls);
+        }
+        while (l2.back() > max_run) {
+            const int64_t rest = l2.back() - max_run, at = s2.back() + max_run;
+            l2.back() = max_run;
+            s2.push_back(at);
+            l2.push_back(rest);
+            e2.push_back(cls);
         }
     }
     start.swap(s2);
     len.swap(l2);
-    poff.assign(start.size() + 1, 0);
-    for (size_t i = 0; i < start.size(); ++i) poff[i + 1] = poff[i] + len[i];
-    // a run longer than a ring slot is split so that every chunk fits
-    chunk_run.clear();
-    chunk_run.push_back(0);
-    int64_t base = 0;
-    for (size_t i = 0; i < start.size(); ++i) {
-        if (len[i] > chunk_doubles) throw std::runtime_error("XferPlan: run longer than a ring slot");
-        if (poff[i + 1] - base > chunk_doubles) {
-            chunk_run.push_back(i);
-            base = poff[i];
+    early.swap(e2);
+    // packed order: the early runs interval by interval, then everything else in slab order
+    const size_t nr = start.size();
+    std::vector<size_t> order(nr);
+    for (size_t i = 0; i < nr; ++i) order[i] = i;
+    auto key = [&](size_t i) { return early[i] >= 0 ? (int64_t)early[i] : n_int; };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key(a) < key(b); });
+    pk_start.resize(nr);
+    pk_len.resize(nr);
+    pk_poff.assign(nr + 1, 0);
+    early_off.assign((size_t)n_int + 1, 0);
+    for (size_t i = 0; i < nr; ++i) {
+        pk_start[i] = start[order[i]];
+        pk_len[i] = len[order[i]];
+        pk_poff[i + 1] = pk_poff[i] + pk_len[i];
+        if (early[order[i]] >= 0) {
+            if (early[order[i]] >= n_int) throw std::runtime_error("XferPlan: early run of an interval the shard does not own");
+            ++early_off[(size_t)early[order[i]] + 1];
         }
     }
-    chunk_run.push_back(start.size());
+    for (int64_t i = 0; i < n_int; ++i) early_off[(size_t)i + 1] += early_off[(size_t)i];
+    built = true;
 }
 
 HostPool::HostPool(int n_threads) {
@@ -93,21 +113,41 @@ static int pool_threads() {
     return std::max(2, std::min(n, 12));  // the box's share for one GPU is 16 cores; leave some to the caller
 }
 
-HostXfer::HostXfer() : pool_(pool_threads()) {
+HostXfer::HostXfer() : pool_(pool_threads()), busy_(new std::atomic<int>[SLOTS]) {
+    hip_check(hipGetDevice(&device_), "hipGetDevice");
+    hip_check(hipStreamCreateWithFlags(&copy_, hipStreamNonBlocking), "hipStreamCreate (copy stream)");
     for (int i = 0; i < SLOTS; ++i) {
+        busy_[i] = 0;
         hip_check(hipHostMalloc((void**)&pinned_[i], CHUNK_DOUBLES * sizeof(double)), "hipHostMalloc (D2H ring)");
         hip_check(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming), "hipEventCreate");
     }
+    drainer_ = std::thread([this] { drain_loop(); });
 }
 HostXfer::~HostXfer() {
-    pool_.wait_all();
+    abort();
+    {
+        std::lock_guard<std::mutex> g(m_);
+        stop_ = true;
+    }
+    cv_task_.notify_all();
+    drainer_.join();
     for (int i = 0; i < SLOTS; ++i) {
         if (pinned_[i]) (void)hipHostFree(pinned_[i]);
         if (ev_[i]) (void)hipEventDestroy(ev_[i]);
     }
+    for (hipEvent_t e : ready_pool_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : session_events_) (void)hipEventDestroy(e);
+    if (copy_) (void)hipStreamDestroy(copy_);
 }
 
-void HostXfer::fill_constants_async(const XferPlan& p, double* vals) {
+void HostXfer::begin(const XferPlan& p, const double* d_slab, double* vals) {
+    plan_ = &p;
+    d_slab_ = d_slab;
+    vals_ = vals;
+    {
+        std::lock_guard<std::mutex> g(m_);
+        error_ = nullptr;
+    }
     // gaps between the runs, cut into pieces of about equal size
     const size_t nr = p.start.size();
     const int pieces = std::max(1, pool_.size() * 4);
@@ -135,56 +175,140 @@ void HostXfer::fill_constants_async(const XferPlan& p, double* vals) {
     }
 }
 
-void HostXfer::fetch(const XferPlan& p, const double* d_slab, double* vals, hipStream_t st) {
-    const int64_t nr = (int64_t)p.start.size();
-    if (nr > 0) launch_pack_runs(st, d_slab, p.d_start, p.d_len, p.d_poff, nr, p.d_packed);
-    hip_check(hipGetLastError(), "pack launch");
-    const size_t nchunks = p.chunk_run.empty() ? 0 : p.chunk_run.size() - 1;
-    std::vector<std::atomic<int>> left(nchunks);
-    std::mutex m;
-    std::condition_variable cv;
-    auto chunk_done = [&](size_t c) {
-        if (left[c].fetch_sub(1) == 1) {
-            std::lock_guard<std::mutex> g(m);
-            cv.notify_all();
-        }
-    };
-    // copy of chunk c into its ring slot (waits until the slot's previous tenant has been scattered)
-    auto enqueue = [&](size_t c) {
-        const size_t r0 = p.chunk_run[c], r1 = p.chunk_run[c + 1];
-        left[c] = 0;
-        if (r0 == r1) return;
-        const int slot = (int)(c % SLOTS);
-        if (c >= (size_t)SLOTS) {
-            std::unique_lock<std::mutex> g(m);
-            cv.wait(g, [&] { return left[c - SLOTS].load() == 0; });
-        }
-        const int64_t base = p.poff[r0], cnt = p.poff[r1] - base;
-        left[c] = std::max(1, std::min<int>(pool_.size(), (int)((r1 - r0 + 255) / 256)));
-        hip_check(hipMemcpyAsync(pinned_[slot], p.d_packed + base, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, st), "D2H chunk");
-        hip_check(hipEventRecord(ev_[slot], st), "hipEventRecord");
-    };
-    if (nchunks > 0) enqueue(0);
-    for (size_t c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) enqueue(c + 1);  // keeps the copy engine busy while chunk c is scattered
-        const size_t r0 = p.chunk_run[c], r1 = p.chunk_run[c + 1];
-        if (r0 == r1) continue;
-        const int slot = (int)(c % SLOTS);
-        hip_check(hipEventSynchronize(ev_[slot]), "hipEventSynchronize (D2H chunk)");
-        const int parts = left[c].load();
-        const size_t per = (r1 - r0 + parts - 1) / parts;
-        const int64_t base = p.poff[r0];
-        const double* src = pinned_[slot];
-        for (int q = 0; q < parts; ++q) {
-            const size_t a = std::min(r1, r0 + (size_t)q * per), b = std::min(r1, a + per);
-            pool_.submit([&p, vals, a, b, base, src, c, &chunk_done] {
-                for (size_t r = a; r < b; ++r)
-                    memcpy(vals + p.start[r], src + (p.poff[r] - base), sizeof(double) * (size_t)p.len[r]);
-                chunk_done(c);
-            });
-        }
+void HostXfer::submit(int64_t r0, int64_t r1, hipStream_t producer) {
+    if (!plan_ || r0 >= r1) return;
+    hipEvent_t e;
+    if (!ready_pool_.empty()) {
+        e = ready_pool_.back();
+        ready_pool_.pop_back();
+    } else {
+        hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    }
+    session_events_.push_back(e);
+    hip_check(hipEventRecord(e, producer), "hipEventRecord (slab slice ready)");
+    {
+        std::lock_guard<std::mutex> g(m_);
+        tasks_.push_back(Task{r0, r1, e});
+        working_ = true;
+    }
+    cv_task_.notify_all();
+}
+
+void HostXfer::finish() {
+    {
+        std::unique_lock<std::mutex> g(m_);
+        cv_idle_.wait(g, [this] { return !working_; });
     }
     pool_.wait_all();
+    for (hipEvent_t e : session_events_) ready_pool_.push_back(e);
+    session_events_.clear();
+    plan_ = nullptr;
+    std::exception_ptr err;
+    {
+        std::lock_guard<std::mutex> g(m_);
+        err = error_;
+        error_ = nullptr;
+    }
+    if (err) std::rethrow_exception(err);
+}
+
+void HostXfer::abort() noexcept {
+    try {
+        finish();
+    } catch (...) {
+    }
+}
+
+void HostXfer::drain_loop() {
+    (void)hipSetDevice(device_);
+    for (;;) {
+        Task t{};
+        bool have = false;
+        {
+            std::unique_lock<std::mutex> g(m_);
+            if (tasks_.empty() && inflight_.empty()) {
+                working_ = false;
+                cv_idle_.notify_all();
+                cv_task_.wait(g, [this] { return stop_ || !tasks_.empty(); });
+                if (tasks_.empty()) return;  // stop
+            }
+            if (!tasks_.empty()) {
+                t = tasks_.front();
+                tasks_.pop_front();
+                have = true;
+            }
+        }
+        try {
+            bool failed;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                failed = (bool)error_;
+            }
+            if (failed) {
+                inflight_.clear();  // a session that failed only has to come to rest
+                continue;
+            }
+            if (have) run_task(t);
+            else retire_one();
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m_);
+            if (!error_) error_ = std::current_exception();
+            inflight_.clear();
+        }
+    }
+}
+
+void HostXfer::wait_slot(int slot) {
+    std::unique_lock<std::mutex> g(m_);
+    cv_slot_.wait(g, [&] { return busy_[slot].load() == 0; });
+}
+
+void HostXfer::run_task(const Task& t) {
+    const XferPlan& p = *plan_;
+    hip_check(hipStreamWaitEvent(copy_, t.ready, 0), "hipStreamWaitEvent (copy stream)");
+    launch_pack_runs(copy_, d_slab_, p.d_start + t.r0, p.d_len + t.r0, p.d_poff + t.r0, t.r1 - t.r0, p.d_packed);
+    hip_check(hipGetLastError(), "pack launch");
+    int64_t r = t.r0;
+    while (r < t.r1) {
+        // as many whole runs as fit a ring slot
+        const int64_t base = p.pk_poff[(size_t)r];
+        int64_t e = (std::upper_bound(p.pk_poff.begin() + r, p.pk_poff.begin() + t.r1 + 1, base + CHUNK_DOUBLES) - p.pk_poff.begin()) - 1;
+        if (e <= r) throw std::runtime_error("HostXfer: run longer than a ring slot");
+        const int slot = (int)(piece_seq_++ % SLOTS);
+        wait_slot(slot);  // the piece that used this slot SLOTS pieces ago has been scattered
+        hip_check(hipMemcpyAsync(pinned_[slot], p.d_packed + base, sizeof(double) * (size_t)(p.pk_poff[(size_t)e] - base), hipMemcpyDeviceToHost, copy_),
+                  "D2H piece");
+        hip_check(hipEventRecord(ev_[slot], copy_), "hipEventRecord");
+        inflight_.push_back(Piece{slot, r, e});
+        while (inflight_.size() > 1) retire_one();  // scatter the previous piece while this one is on the wire
+        r = e;
+    }
+}
+
+void HostXfer::retire_one() {
+    const Piece pc = inflight_.front();
+    inflight_.pop_front();
+    hip_check(hipEventSynchronize(ev_[pc.slot]), "hipEventSynchronize (D2H piece)");
+    const XferPlan& p = *plan_;
+    const int64_t nr = pc.r1 - pc.r0;
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(pool_.size(), (nr + 255) / 256));
+    const int64_t per = (nr + parts - 1) / parts;
+    const int64_t base = p.pk_poff[(size_t)pc.r0];
+    const double* src = pinned_[pc.slot];
+    double* vals = vals_;
+    busy_[pc.slot] = parts;
+    for (int q = 0; q < parts; ++q) {
+        const int64_t a = std::min(pc.r1, pc.r0 + (int64_t)q * per), b = std::min(pc.r1, a + per);
+        const int slot = pc.slot;
+        pool_.submit([this, &p, vals, a, b, base, src, slot] {
+            for (int64_t r = a; r < b; ++r)
+                memcpy(vals + p.pk_start[(size_t)r], src + (p.pk_poff[(size_t)r] - base), sizeof(double) * (size_t)p.pk_len[(size_t)r]);
+            if (busy_[slot].fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> g(m_);
+                cv_slot_.notify_all();
+            }
+        });
+    }
 }
 
 }  // namespace dto

@@ -323,6 +323,19 @@ def test_host_pointer_hand_off_ships_only_what_changes():
             outs.append((j, h))
             ev.close()
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # the general path hands the -E_k blocks over chain chunk by chain chunk (four chunks from 512 intervals on), whole and
+    # as a shard whose first interval is not the problem's first
+    p = O.make_scaled_problem(600, 40, 2, seed=5)
+    for lo, hi in ((1, 600), (31, 590)):
+        outs = []
+        for on in (1, 0):
+            ev = dto_amd.Evaluator(to_engine(p), eval_hessian=False, k_lo=lo, k_hi=hi)
+            ev.set_option("host_xfer", on)
+            for rep in range(2):
+                j = np.full(ev.shard.jac_len, np.nan); ev.eval_constraint_jacobian(j, p.Z0 + 0.001 * rep)
+            outs.append(j)
+            ev.close()
+        assert np.array_equal(outs[0], outs[1])
     # shards too
     p = O.make_scaled_problem(11, 8, 2, seed=3, with_constraint=True)
     for lo, hi in ((1, 4), (5, 11)):
