@@ -68,6 +68,27 @@ def gather_slabs_inplace(full, layout, group=None):
     return full
 
 
+def gather_slabs_async(full, layout, group=None):
+    """The in-place gather as asynchronous collectives: one broadcast per rank, enqueued behind the work that is on the
+    current stream NOW (the rank's own slab), running on the backend's own stream next to whatever is enqueued afterwards.
+    Returns the work handles; `wait()` on each makes the current stream wait for it.
+
+    This is how the gather overlaps with compute: a rank splits its knot range over two or more
+    engine handles (`split_range`), and while handle i+1 computes, the slabs of handle i are already on the links."""
+    import torch.distributed as dist
+    works = []
+    for r, (lo, n) in enumerate(layout):
+        if n:
+            src = dist.get_global_rank(group, r) if group is not None else r
+            works.append(dist.broadcast(full[lo:lo + n], src=src, group=group, async_op=True))
+    return works
+
+
+def split_range(k_lo, k_hi, parts):
+    """Contiguous, balanced 1-based inclusive sub-ranges of [k_lo, k_hi] (a rank's knots over `parts` handles)."""
+    return [(k_lo + a - 1, k_lo + b - 1) for a, b in shard_ranges(k_hi - k_lo + 1, parts)]
+
+
 def allreduce_sum(t, group=None):
     import torch.distributed as dist
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
