@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--no-other-callbacks", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="leave the engine's HIP-event kernel timing off (measures its cost; the roofline block is then empty)")
+    ap.add_argument("--serial-kernels", action="store_true",
+                    help="option overlap_sweep = 0 for the whole run: the generator sweep no longer shares the chip with the chain's "
+                         "products, per-kernel durations are clean (the command to put under rocprofv3)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo lets several ranks share one GPU in rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -291,6 +294,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.serial_kernels:
+        ev.set_option("overlap_sweep", 0)
     ev.profile_enable(not args.no_kernel_timing)  # warm-up runs with the timing events on too; they are recycled by profile_reset
     for _ in range(args.warmup):
         step()
@@ -307,21 +312,51 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms_gemm, n_gemm, fl_gemm = ev.profile_get("bgemm")
-    ms_sweep, n_sweep, fl_sweep = ev.profile_get("expmv")
-    variants = {}
-    for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("basis", "basis")):
-        ms_v, n_v, fl_v = ev.profile_get(nm)
-        if n_v:
-            variants[key] = {"launches": n_v, "avg_launch_ms": ms_v / n_v, "tflops": fl_v / (ms_v * 1e-3) / 1e12}
-            # the polynomial products ("horner") also sit on the HBM roof: per launch two operands, three or four power
-            # matrices in the epilogue and one or two outputs -- seven npad x npad matrices per interval in each of the
-            # three launches of the order-26 form; a squaring moves two
-            streams = {"horner": 7, "square": 2}.get(key)
-            if streams and (n, Nk) == (256, 2000):
-                gbs = streams * 8.0 * n * n * (Nk - 1) / (ms_v / n_v * 1e-3) / 1e9
-                variants[key].update({"algorithmic_hbm_bytes": streams * 8.0 * n * n * (Nk - 1), "hbm_gbs": gbs,
-                                      "hbm_frac": gbs / HBM_PEAK_GBS})
+    def collect():
+        """HIP-event figures of the engine's kernels since the last profile_reset."""
+        ms_g, n_g, fl_g = ev.profile_get("bgemm")
+        ms_s, n_s, fl_s = ev.profile_get("expmv")
+        var = {}
+        for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("basis", "basis")):
+            ms_v, n_v, fl_v = ev.profile_get(nm)
+            if n_v:
+                var[key] = {"launches": n_v, "avg_launch_ms": ms_v / n_v, "tflops": fl_v / (ms_v * 1e-3) / 1e12}
+                # the polynomial products ("horner") also sit on the HBM roof: per launch two operands, three or four power
+                # matrices in the epilogue and one or two outputs -- seven npad x npad matrices per interval in each of the
+                # three launches of the order-26 form (DESIGN.md section 4.3); a squaring moves two
+                streams = {"horner": 7, "square": 2}.get(key)
+                if streams and (n, Nk) == (256, 2000):
+                    gbs = streams * 8.0 * n * n * (Nk - 1) / (ms_v / n_v * 1e-3) / 1e9
+                    var[key].update({"algorithmic_hbm_bytes": streams * 8.0 * n * n * (Nk - 1), "hbm_gbs": gbs,
+                                     "hbm_frac": gbs / HBM_PEAK_GBS})
+        return ms_g, n_g, fl_g, ms_s, n_s, fl_s, var
+
+    ms_gemm, n_gemm, fl_gemm, ms_sweep, n_sweep, fl_sweep, variants = collect()
+    # In the timed region the Jacobian's generator sweep shares the chip with the chain's products (option overlap_sweep, on
+    # by default): a kernel's HIP-event duration there includes what it waited for the other stream.  The roofline of the
+    # dominant kernel is therefore taken from a SERIAL pass -- the same K steps again with overlap_sweep = 0, one kernel at
+    # a time, which is also what `rocprofv3 -- python3 bench.py --serial-kernels` shows (profiles/) -- and the timed
+    # region's own figures are reported next to it.
+    overlapped = None
+    if args.callback == "jacobian" and not args.serial_kernels and not args.no_kernel_timing:
+        overlapped = {"avg_launch_ms": ms_gemm / max(n_gemm, 1), "launches": n_gemm,
+                      "achieved": fl_gemm / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0,
+                      "sweep_ms_per_step": ms_sweep / args.steps,
+                      "note": "k_bgemm launches of the timed region: the sweep runs next to them on a second stream"}
+        ev.set_option("overlap_sweep", 0)
+        ev.profile_enable(True)
+        step()
+        fence()
+        ev.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        serial_elapsed = time.perf_counter() - t0
+        ev.profile_enable(False)
+        ev.set_option("overlap_sweep", 1)
+        ms_gemm, n_gemm, fl_gemm, ms_sweep, n_sweep, fl_sweep, variants = collect()
+        overlapped["ms_per_step_serial_pass"] = serial_elapsed / args.steps * 1e3
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
 
@@ -371,8 +406,13 @@ def main():
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": n_gemm, "avg_launch_ms": ms_gemm / max(n_gemm, 1),
                 "flops_per_launch": fl_gemm / max(n_gemm, 1),
-                "share_of_step": ms_gemm / (ms_per_step * args.steps) if ms_per_step > 0 else None,
+                "share_of_step": ms_gemm / ((overlapped["ms_per_step_serial_pass"] if overlapped else ms_per_step) * args.steps)
+                if ms_per_step > 0 else None,
                 "template_instances": variants,
+                "measured_in": ("serial pass: the K steps again with option overlap_sweep = 0 (one kernel at a time), HIP events "
+                                "on the launch stream; same as rocprofv3 of `bench.py --serial-kernels`" if overlapped else
+                                "the timed region"),
+                "timed_region": overlapped,
             },
             # the whole callback against the HBM roofline (BASELINE north_star asks for this fraction too): algorithmic
             # bytes = mandatory output write + read of Z + one read of the generators

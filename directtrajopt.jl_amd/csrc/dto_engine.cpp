@@ -212,6 +212,7 @@ struct dto_handle {
     std::vector<hipEvent_t> ev_pool;  // recycled timing events (creating them inside the timed region costs host time)
     int last_smax = 0, last_terms = 0;
     int expm_form = 0;  // option "expm_form": 0 = by cost, 2 / 3 = forced
+    int overlap_sweep = 1;  // option "overlap_sweep": the Jacobian's generator sweep on a second stream next to the chain's products
     int sweep_form = 0;   // option "sweep_form": 0 = fused persistent sweep where it applies, 1 = step-per-launch form only
     int n_cu = 256;
     int chain_chunk = 0;  // option "chain_chunk": upper bound on the intervals per chain chunk (0: workspace capacity)
@@ -992,7 +993,11 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
             // generator-norm bounds: enqueued here, read inside the chain's own readback point (no stream sync of their
             // own); the squaring cap they used to provide is the constant 60, a NaN iterate gets one squaring
             enqueue_bounds(h, b, dZ, st);
-            static const bool overlap = tune_int("DTO_OVERLAP", 0) != 0;  // off by default: +2% end to end, but per-kernel timings blur
+            // The sweep (one persistent launch, no HBM traffic to speak of) runs on the second stream next to the polynomial
+            // products and squarings of the chain: its 223 workgroups leave 33 CUs idle and every chain launch has a tail --
+            // together 5-6 % of the call (12.3 -> 11.5 ms at 256 x 2000).  Option "overlap_sweep" = 0 runs one kernel at a
+            // time (per-kernel timings mean something only then).
+            const bool overlap = h->overlap_sweep != 0;
             hipStream_t ss = overlap ? h->stream2 : st;
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
@@ -2259,6 +2264,10 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
     if (std::string(name) == "reuse_forward_sweep") {
         h->reuse = value != 0;
         drop_caches(h);
+        return 0;
+    }
+    if (std::string(name) == "overlap_sweep") {
+        h->overlap_sweep = value != 0;
         return 0;
     }
     if (std::string(name) == "sweep_form") {

@@ -480,9 +480,11 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
     bool found = false;
     double best = 0.0;
     static const double l2_factor[4] = {0.0, 1.6, 1.15, 1.0};
+    static const int ipw_env = tune_int("DTO_SWEEP_IPW", 0);  // A/B runs (TUNING builds)
     for (int ipw = 1; ipw <= 48; ++ipw) {
         const int NC = T * ipw, NT = (NC + 15) / 16;
         if (NT > 3) break;
+        if (ipw_env > 0 && ipw != ipw_env && T == 1 + m) continue;
         const FusedLds L(npad, T, m, ipw, nslot, MT);
         const size_t bytes = (size_t)L.total * sizeof(double);
         if (bytes > 156 * 1024) break;
