@@ -8,8 +8,8 @@ import sys
 
 def main():
     tag, stats = sys.argv[1], sys.argv[2]
-    out = [f"# rocprofv3 summary {tag}", "", "command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
-           "(7 eval_constraint_jacobian calls, 256-state x 2000-knot bilinear, 1x MI355X)", "",
+    out = [f"# rocprofv3 summary {tag}", "", "command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-callbacks --serial-kernels`",
+           "(7 eval_constraint_jacobian calls, 256-state x 2000-knot bilinear, 1x MI355X; --serial-kernels = option overlap_sweep 0, one kernel at a time)", "",
            "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for r in list(csv.DictReader(open(stats)))[:16]:
         out.append("| `%s` | %s | %.3f | %.1f | %s |" % (r["Name"][:80].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
