@@ -71,7 +71,7 @@ __device__ __forceinline__ void gemm_accumulate_s(GemmAccS<C>& acc, const double
                                                   const double* __restrict__ colscale, double* smem,
                                                   const double* __restrict__ B2 = nullptr,
                                                   const double* __restrict__ colscale2 = nullptr) {
-    constexpr int TM = C::TM, TN = C::TN;
+    constexpr int TM = C::TM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;

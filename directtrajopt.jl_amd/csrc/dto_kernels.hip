@@ -666,6 +666,7 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
     }
     if (a.npad % 256 == 0) {
         // shapes measured with tools/bgemm_probe2 (256x2000): see DESIGN.md
+#ifdef DTO_TUNING  // the alternative shapes exist in `make TUNING=1` builds only
         switch (bgemm_shape_choice()) {
             case 0: launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2); return;
             case 1: launch_bgemm_shape<GemmShape<128, 128, 2, 2, 8>, EPI>(st, a, 2); return;
@@ -676,13 +677,13 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
             case 6: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2); return;
             case 7: launch_bgemm_shape<GemmShape<128, 128, 4, 2, 16>, EPI>(st, a, 2); return;
             case 8: launch_bgemm_shape<GemmShape<128, 128, 2, 4, 8>, EPI>(st, a, 3); return;
-            default:
-                // measured in the engine (256x2000): the fused-polynomial epilogue hides better behind 8 waves,
-                // the plain / squaring products run faster with 4 waves of 64x64
-                if (epi_poly(EPI)) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
-                else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
-                return;
+            default: break;
         }
+#endif
+        // measured in the engine (256x2000): the fused-polynomial epilogue hides better behind 8 waves,
+        // the plain / squaring products run faster with 4 waves of 64x64
+        if (epi_poly(EPI)) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
+        else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
     } else if (a.npad % 128 == 0) {
         if (epi_poly(EPI)) launch_bgemm_shape<GemmShape<128, 128, 2, 4, 16>, EPI>(st, a, 2);
         else launch_bgemm_shape<GemmShape<128, 128, 2, 2, 16>, EPI>(st, a, 2);
@@ -1373,7 +1374,7 @@ __global__ void __launch_bounds__(256) k_hess_pair(KProb P, KBil B, SweepBuf fw,
     const int64_t kl = blockIdx.x;
     const int64_t kn = P.kn_lo + kl;
     constexpr int m = M;  // drives: compile-time so that the accumulators live in registers
-    const int n = B.n, npad = fw.npad, T = 1 + m;
+    const int npad = fw.npad, T = 1 + m;
     const int64_t typesz = (int64_t)fw.Kpad * npad;
     const int64_t tstride = (int64_t)T * typesz;          // one stored Taylor term of all forward types
     const int64_t gstride = (int64_t)nf_used * typesz;    // one generator in EP (nf_used terms)

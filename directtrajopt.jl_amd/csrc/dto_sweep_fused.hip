@@ -54,7 +54,8 @@ constexpr int PF = 4;  // k-steps (of 4) the A fragments are loaded ahead
 struct FusedLds {
     int zs, scr, cg, se, tn, sn, xn, xg, xs, xm, flag, total;  // offsets in doubles
     __host__ __device__ FusedLds(int npad, int T, int m, int ipw, int nslot, int MT) {
-        const int NC = T * ipw, ZS = npad + 2, RL = 16 * MT;
+        const int NC = T * ipw, ZS = npad + 2;
+        (void)nslot; (void)MT;
         int o = 0;
         zs = o; o += NC * ZS + 4;  // + 4: the B-fragment prefetch runs one k-step past the last column
         scr = o;
