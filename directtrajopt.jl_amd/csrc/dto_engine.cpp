@@ -488,6 +488,15 @@ SweepPlan plan_sweep(double beta) {
     return p;
 }
 
+// Taylor steps a fused sweep (already enqueued on st) actually took: waits for it.
+int fused_sweep_steps(dto_handle* h, const SweepBuf& w, int d_ub, hipStream_t st) {
+    int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 6);
+    HIP_CHECK(hipMemcpyAsync(hs, w.stats, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return std::max(1, std::min(hs[1] - 1, d_ub));
+}
+bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store);
+
 // Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
@@ -508,8 +517,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
     // step-per-launch form below remains for single-type sweeps (split-K over the generators serves those better), for
     // sweeps over frozen p terms and for the products' extra start vector.
     FusedSweepPlan fp;
-    if (h->sweep_form != 1 && !w.frozen && !skip_init && ty.T >= 2 && (!store || (w.Zt && plan.d_ub + 1 <= w.dcap)) &&
-        sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp)) {
+    if (!skip_init && fused_sweep_applies(h, b, w, ty, plan, store) && sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp)) {
         w.nblk = fp.ipw;
         HIP_CHECK(hipMemsetAsync(w.stats, 0, 4 * sizeof(int32_t), st));
         {
@@ -518,10 +526,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
             HIP_CHECK(launch_sweep_fused(st, h->P, b.k, w, ty, fp, dZ, dmu, src_kind, transposed, plan.q, plan.d_ub, tc, store, 1.1e-16));
         }
         if (!want_steps) return plan.d_ub;
-        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 6);
-        HIP_CHECK(hipMemcpyAsync(hs, w.stats, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        return std::max(1, std::min(hs[1] - 1, plan.d_ub));
+        return fused_sweep_steps(h, w, plan.d_ub, st);
     }
     w.nblk = w.TN;
     const size_t tstride = (size_t)ty.T * w.Kpad * w.npad;
@@ -794,6 +799,12 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     return d2max;
 }
 
+bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store) {
+    FusedSweepPlan fp;
+    return h->sweep_form != 1 && !w.frozen && ty.T >= 2 && (!store || (w.Zt && plan.d_ub + 1 <= w.dcap)) &&
+           sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp);
+}
+
 // max_k ||A_k^2||_1^(1/2), exact, for callbacks that do not run the propagator chain: A_k and A_k^2 only
 // (one streaming pass + one small GEMM per chunk).  Sharper than the generator-norm bound, so the sweep
 // usually needs a single round (q = 1).
@@ -1063,6 +1074,20 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             const bool pair = b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
             const int m = b.k.m, T1 = 1 + m;
             int steps_f, Tf = T1;  // Tf: types per stored forward term
+            SweepTypes ty1 = make_types(m, false);
+            // Pairing path with a forward sweep of its own: the adjoint sweep is one persistent launch that leaves CUs idle, the
+            // forward sweep of the p column a host-driven sequence of small launches -- independent until the pairing kernels,
+            // so the adjoint sweep is enqueued first and the forward sweep runs next to it on the second stream.
+            const bool fwd_needed = pair && !(same && (b.cache_kind == 3 || b.p_terms));
+            const bool side_by_side = fwd_needed && h->overlap_sweep && fused_sweep_applies(h, b, b.ad, ty1, plan, true);
+            bool adjoint_enqueued = false;
+            if (side_by_side) {
+                HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ, dmu and the zeroed slab are ready here
+                HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, true, false, /*want_steps=*/false);
+                adjoint_enqueued = true;
+            }
+            hipStream_t sf = side_by_side ? h->stream2 : st;
             if (pair) {
                 // Pairing path: every tangent comes from the ADJOINT sweep (the (x,u) block needs those anyway); of the forward
                 // sweep only the Taylor terms of the p column are used (k_hess_pair, k_hess_bilinear).
@@ -1073,12 +1098,16 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                     steps_f = b.p_steps;      // eval_constraint (or an earlier Hessian) stored the p terms of this point
                 } else {
                     Tf = 1;
-                    steps_f = run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, plan, st, true);
+                    steps_f = run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, plan, sf, true);
                     b.cache_kind = h->reuse ? 1 : 0;  // the p sums are valid, the tangent sums are not
                     b.cache_steps = steps_f;
-                    remember_p_terms(h, b, true, steps_f, st);
+                    remember_p_terms(h, b, true, steps_f, sf);
                 }
-                launch_apply_generators(st, b.k, b.fw, 0, b.fw.Zt, b.fw.W);  // V_l = G_l x (term 0 of the p column is x)
+                launch_apply_generators(sf, b.k, b.fw, 0, b.fw.Zt, b.fw.W);  // V_l = G_l x (term 0 of the p column is x)
+                if (side_by_side) {
+                    HIP_CHECK(hipEventRecord(h->ev_join, sf));
+                    HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+                }
             } else {
                 steps_f = run_sweep(h, b, b.fw, make_types(m, true), dZ, nullptr, 0, 0, plan, st, false);
                 launch_apply_Gu(st, b.k, b.fw, 0, b.fw.S, b.fw.GY);
@@ -1088,8 +1117,8 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 launch_sweep_init(st, h->P, b.k, b.ad, make_types(0, false), dZ, dmu, 1, plan.q);
                 launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
             }
-            SweepTypes ty1 = make_types(m, false);
-            const int steps_a = run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair, false, /*want_steps=*/pair);
+            const int steps_a = adjoint_enqueued ? fused_sweep_steps(h, b.ad, plan.d_ub, st)
+                                                 : run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair, false, /*want_steps=*/pair);
             launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
             launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
             if (pair) {

@@ -373,3 +373,19 @@ def test_sweep_on_the_second_stream_changes_no_bit():
         ev.close()
         assert bool(torch.isfinite(outs[0]).all())
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # the Hessian's forward sweep next to its adjoint sweep (same option): accumulated with floating-point atomics, so equal
+    # to rounding rather than to the bit
+    p = O.make_scaled_problem(1200, 64, 3, seed=11)
+    ev = dto_amd.Evaluator(to_engine(p))
+    Z = torch.from_numpy(p.Z0).to(dev)
+    mu = torch.from_numpy(np.random.default_rng(2).standard_normal(ev.n_constraints)).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    outs = []
+    for on in (1, 0):
+        ev.set_option("overlap_sweep", on)
+        o = torch.full((ev.shard.hess_len,), float("nan"), dtype=torch.float64, device=dev)
+        ev.eval_hessian_dev(Z.data_ptr(), 0.9, mu.data_ptr(), o.data_ptr(), st)
+        torch.cuda.synchronize()
+        outs.append(o.cpu().numpy())
+    ev.close()
+    assert np.isfinite(outs[0]).all() and rel_err(outs[0], outs[1]) <= 1e-12
