@@ -376,6 +376,12 @@ def main():
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_k_bgemm.json")))
         if (n, Nk, args.callback) == (256, 2000, "jacobian"):
             traffic, traffic_src = tj["avg_per_launch_bytes"], tj["source"]
+            pl = tj["per_launch_bytes"]
+            prods = [v["read"] + v["write"] for k, v in pl.items() if k.startswith("product")]
+            if "horner" in variants and prods:
+                variants["horner"]["traffic"] = sum(prods) / len(prods)
+            if "square" in variants and "square" in pl:
+                variants["square"]["traffic"] = pl["square"]["read"] + pl["square"]["write"]
     except Exception:
         pass
     if rank == 0:
