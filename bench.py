@@ -225,7 +225,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256, help="state dimension")
+    ap.add_argument("--n", "--states", dest="n", type=int, default=256,
+                    help="state dimension (--states under torch.distributed.run, whose parser takes --n for its own)")
     ap.add_argument("--m", type=int, default=4, help="number of drives")
     ap.add_argument("--knots", type=int, default=2000, help="knots per GPU")
     ap.add_argument("--callback", default="jacobian", choices=["jacobian", "hessian", "constraint"])

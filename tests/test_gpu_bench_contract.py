@@ -1,0 +1,57 @@
+"""GPU: `bench.py` honours the driver's contract on a small shape -- one JSON line on stdout with the required keys, the
+roofline block (serial pass) and the CPU baseline block; and the two-rank one-device rehearsal of the multi-GPU path prints
+the gather block (sequential and overlapped forms)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n", "64", "--knots", "1200",
+                        "--cpu-budget", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["value"] > 0
+    assert abs(d["value"] - 1200 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and rf["launches"] > 0
+    assert rf["timed_region"]["launches"] == rf["launches"]          # the serial pass repeats the timed region's launches
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["config"]["outputs_finite"] is True
+
+
+def test_two_ranks_on_one_device_print_the_gather_block():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--states", "64", "--knots", "600", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["knots_total"] == 1200 and d["scaling"] == "weak"
+    g = d["gather"]
+    assert "error" not in g and "overlapped_error" not in g, g
+    assert g["n_ranks"] == 2 and g["sampled_finite"] is True
+    assert g["ms_per_step_overlapped"] > 0 and g["overlapped_vs_sequential_max_rel_diff_sampled"] <= 1e-10
