@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(WR * WC * 64, MINW) k_gemm(const double* A, co
 }
 
 template <int TM, int TN, int WR, int WC, int KB, int DBG, int MINW>
-void run(const char* name, const double* A, const double* B, double* C, int npad, int nb, int wgs_per_cu) {
+void run(const char* name, const double* A, const double* B, double* C, int npad, int nb, int wgs_per_cu, int reps = 5) {
     const int tpm = (npad / TM) * (npad / TN), total = ((nb + 7) / 8) * 8 * tpm;
     const int grid = std::min(total, wgs_per_cu * 256);
     unsigned long long* st;
@@ -133,7 +133,6 @@ void run(const char* name, const double* A, const double* B, double* C, int npad
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k, dim3(grid), dim3(WR * WC * 64), 0, 0, A, B, C, npad, nb, st);
     hipEventRecord(e0);
-    const int reps = 5;
     for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(k, dim3(grid), dim3(WR * WC * 64), 0, 0, A, B, C, npad, nb, (unsigned long long*)nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
@@ -148,7 +147,10 @@ void run(const char* name, const double* A, const double* B, double* C, int npad
 }
 
 int main(int argc, char** argv) {
-    const int npad = 256, nb = 2000;
+    // usage: bgemm_probe2 [nbatch reps]: with arguments only the production shapes run, on nbatch matrices -- e.g. 128 (operands and
+    // output 192 MB: resident in the 256 MB Infinity Cache across the repetitions) against 2000 (3 GB: streamed from HBM)
+    const int npad = 256, nb = argc > 1 ? atoi(argv[1]) : 2000;
+    const int reps_arg = argc > 2 ? atoi(argv[2]) : 5;
     const size_t nn = (size_t)npad * npad;
     double *A, *B, *C;
     hipMalloc(&A, nn * nb * 8); hipMalloc(&B, nn * nb * 8); hipMalloc(&C, nn * nb * 8);
@@ -157,6 +159,12 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nb; ++i) {
         hipMemcpy(A + nn * i, h.data() + nn * (i % 7), nn * 8, hipMemcpyHostToDevice);
         hipMemcpy(B + nn * i, h.data() + nn * ((i + 3) % 7), nn * 8, hipMemcpyHostToDevice);
+    }
+    if (argc > 1) {
+        run<128, 128, 2, 2, 16, 0, 2>("128x128 4w KB16 (production)", A, B, C, npad, nb, 2, reps_arg);
+        run<128, 128, 2, 4, 16, 0, 2>("128x128 8w(2x4) KB16 2wg/cu", A, B, C, npad, nb, 2, reps_arg);
+        run<128, 128, 2, 2, 16, 1, 2>("  dbg1: no global loads (4w)", A, B, C, npad, nb, 2, reps_arg);
+        return 0;
     }
     run<128, 128, 2, 2, 16, 0, 2>("128x128 4w KB16 (production)", A, B, C, npad, nb, 2);
     run<128, 128, 2, 2, 16, 1, 2>("  dbg1: no global loads", A, B, C, npad, nb, 2);
