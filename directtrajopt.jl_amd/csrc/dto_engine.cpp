@@ -501,7 +501,7 @@ bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& 
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
               int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false,
-              bool skip_init = false, bool want_steps = false) {
+              bool skip_init = false, bool want_steps = false, bool shared_chip = false) {
     const double flops_step = [&] {
         double segs = 0;
         for (int t = w.frozen ? w.first_type : 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
@@ -517,7 +517,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
     // step-per-launch form below remains for single-type sweeps (split-K over the generators serves those better), for
     // sweeps over frozen p terms and for the products' extra start vector.
     FusedSweepPlan fp;
-    if (!skip_init && fused_sweep_applies(h, b, w, ty, plan, store) && sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp)) {
+    if (!skip_init && fused_sweep_applies(h, b, w, ty, plan, store) && sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp, shared_chip)) {
         w.nblk = fp.ipw;
         HIP_CHECK(hipMemsetAsync(w.stats, 0, 4 * sizeof(int32_t), st));
         {
@@ -1035,7 +1035,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 }
                 // with reuse on and a Hessian to follow, keep every Taylor term so that the Hessian can skip its forward sweep
                 const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
-                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep);
+                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep, false, false, /*shared_chip=*/overlap);
                 launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;

@@ -231,10 +231,11 @@ void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const d
 // ---- the whole sweep in one persistent launch (dto_sweep_fused.hip): a workgroup owns `ipw` intervals, all rows, all types
 struct FusedSweepPlan {
     int MT, NT, ipw, nslot, nblocks;
+    int WC = 1;  // column groups of wavefronts (4 WC wavefronts per workgroup), NT column tiles per group
     size_t lds_bytes;
 };
 hipError_t sweep_fused_prepare();  // per-device opt-in to the kernels' dynamic LDS (dto_create)
-bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, FusedSweepPlan& out);
+bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, FusedSweepPlan& out, bool shared_chip = false);
 // Runs q rounds of at most d_ub Taylor steps (termination test from step tc on, per workgroup), terms into w.Zt (store) or
 // ping-pong w.Z[0/1], sums into w.S, scale factors into w.scale*, valid term counts into w.nterms[workgroup],
 // w.stats[0] += workgroups that did not converge, w.stats[1] = max terms used (the caller zeroes w.stats).

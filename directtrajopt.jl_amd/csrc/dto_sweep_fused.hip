@@ -75,11 +75,15 @@ struct FusedLds {
 // npad == 64 MT: one row pass of the four wavefronts covers the matrix.  The sums live in registers and the new term goes
 // from the accumulators straight into the LDS columns; global memory sees the terms only in store mode and the sums once,
 // at the end.
-template <int MT, int NT>
-__global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
+// WC column groups of wavefronts: wavefront (wr, wc) owns rows 16 MT wr .. and the column tiles NT wc .. NT (wc + 1) - 1; WC = 2
+// puts two wavefronts on every SIMD, each with the k-loop of a two-tile workgroup.
+template <int MT, int NT, int WC>
+__global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) {
+    constexpr int NTHREADS = 256 * WC, NWAVES = 4 * WC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RL = 16 * MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int wr = wave & 3, ct0 = (wave >> 2) * NT;  // row group, first column tile
     const int npad = a.w.npad, Kpad = a.w.Kpad, T = a.ty.T, m = a.B.m, ipw = a.ipw;
     const int NC = T * ipw, ZS = npad + 2, KS = npad / 4;
     const int64_t typesz = (int64_t)Kpad * npad, nn = (int64_t)npad * npad;
@@ -125,13 +129,13 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
         xm[2 * tid] = td.mult[0]; xm[2 * tid + 1] = td.mult[1];
     }
     if (tid < 2) flag[tid] = 0;
-    for (int c = tid; c < 3 * NC; c += 256) tn[c] = 0ull;
-    for (int c = tid; c < NC; c += 256) sn[c] = 0ull;
+    for (int c = tid; c < 3 * NC; c += NTHREADS) tn[c] = 0ull;
+    for (int c = tid; c < NC; c += NTHREADS) sn[c] = 0ull;
     __syncthreads();
     {
         double* Z0 = a.store ? a.w.Zt : a.w.Z[0];
         const bool to_global = a.store != 0;  // without store the terms never leave the CU
-        for (int c = wave; c < NC; c += 4) {
+        for (int c = wave; c < NC; c += NWAVES) {
             const int ty = c / ipw, i = c - ty * ipw, kl = k0 + i;
             const bool live = ty == 0 && kl < a.P.n_int;
             const int64_t kn = a.P.kn_lo + kl;
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
     bool bok[NT];
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) {
-        const int c = 16 * tj + lr;
+        const int c = 16 * (ct0 + tj) + lr;
         bok[tj] = c < NC;
         const int cc = bok[tj] ? c : NC - 1;
         bty[tj] = cc / ipw;
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
 
     // sums of this lane's accumulator elements: element (ti, tj, r) is row rowbase + 32 (ti/2) + 2 lr + (ti & 1) [MT >= 2] of
     // column 16 tj + 4 r + lq
-    const int rowbase = wave * RL;
+    const int rowbase = wr * RL;
     d4 sreg[MT][NT];
     auto lane_row = [&](int ti) { return MT >= 2 ? rowbase + 32 * (ti / 2) + 2 * lr + (ti & 1) : rowbase + lr; };
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 16 * tj + 4 * r + lq;
+                const int c = 16 * (ct0 + tj) + 4 * r + lq;
                 sreg[ti][tj][r] = c < NC ? Zs[c * ZS + lane_row(ti)] : 0.0;
             }
 
@@ -200,11 +204,11 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
                 for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * tj + 4 * r + lq;
+                        const int c = 16 * (ct0 + tj) + 4 * r + lq;
                         if (c < NC) Zs[c * ZS + lane_row(ti)] = sreg[ti][tj][r];
                     }
             __syncthreads();
-            for (int c = wave; c < NC; c += 4) {
+            for (int c = wave; c < NC; c += NWAVES) {
                 double mx = 0.0;
                 for (int r = lane; r < npad; r += 64) mx = fmax(mx, fabs(Zs[c * ZS + r]));
 #pragma unroll
@@ -322,7 +326,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
                 for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * tj + 4 * r + lq;
+                        const int c = 16 * (ct0 + tj) + 4 * r + lq;
                         const int cc = c < NC ? c : 0;
                         const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
                         const bool ok = c < NC && kl < Kpad;
@@ -370,21 +374,21 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
             __syncthreads();  // every wave is done with the old term columns
             // Al-Mohy & Higham's test (as k_sweep_check): two successive terms below tol * |sum| in every column
             if (t >= a.tc) {
-                for (int c = tid; c < NC; c += 256) {
+                for (int c = tid; c < NC; c += NTHREADS) {
                     const double a0 = fbits_to_d(tn[(t % 3) * NC + c]), a1 = fbits_to_d(tn_new[c]), s = fbits_to_d(sn[c]);
                     if (!(a0 + a1 <= a.tol * s) && (a0 + a1 == a0 + a1) && s < 1e300) flag[t & 1] = 1;
                 }
             } else if (tid == 0) {
                 flag[t & 1] = 1;
             }
-            for (int c = tid; c < NC; c += 256) tn[((t + 2) % 3) * NC + c] = 0ull;
+            for (int c = tid; c < NC; c += NTHREADS) tn[((t + 2) % 3) * NC + c] = 0ull;
             if (tid == 0) flag[(t + 1) & 1] = 0;
             // the new term becomes the B operand of the next step
 #pragma unroll
             for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * tj + 4 * r + lq;
+                    const int c = 16 * (ct0 + tj) + 4 * r + lq;
                     if (c < NC) {
                         if constexpr (MT >= 2) {
 #pragma unroll
@@ -408,7 +412,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 16 * tj + 4 * r + lq;
+                const int c = 16 * (ct0 + tj) + 4 * r + lq;
                 const int cc = c < NC ? c : 0;
                 const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
                 if (c < NC && kl < Kpad) {
@@ -431,15 +435,15 @@ __global__ void __launch_bounds__(256, 1) k_sweep_fused(FusedSweepArgs a) {
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int WC = 1>
 hipError_t launch_one(hipStream_t st, const FusedSweepArgs& a, int nblocks, size_t lds) {
     if (a.w.npad != 64 * MT) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_sweep_fused<MT, NT>), dim3(nblocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_sweep_fused<MT, NT, WC>), dim3(nblocks), dim3(256 * WC), lds, st, a);
     return hipGetLastError();
 }
-template <int MT, int NT>
+template <int MT, int NT, int WC = 1>
 hipError_t prepare_one(int bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<MT, NT, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace
@@ -452,12 +456,13 @@ hipError_t sweep_fused_prepare() {
     DTO_PREP(2, 1); DTO_PREP(2, 2); DTO_PREP(2, 3);
     DTO_PREP(1, 1); DTO_PREP(1, 2); DTO_PREP(1, 3);
 #undef DTO_PREP
+    if (e == hipSuccess) e = prepare_one<4, 2, 2>(bytes);
     return e;
 }
 
 // Shape of the launch for a sweep over T column types of an integrator padded to npad states, n_int intervals:
 // intervals per workgroup (ipw) and tile counts.  Returns false when the fused form does not apply.
-bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, FusedSweepPlan& out) {
+bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, FusedSweepPlan& out, bool shared_chip) {
     const int T = ty.T;
     if (T < 1 || n_int <= 0) return false;
     // One row pass must cover the matrix (npad = 64, 128 or 256: 4 wavefronts x 16 MT rows).  Larger matrices offer their
@@ -478,27 +483,40 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
     const int RB = 1;
     // cost model: one workgroup per CU and round; a round takes NT * RB units of MFMA time, and a narrow column tile
     // streams the generators from L2 at 512 / (16 NT) bytes per cycle and CU, which at NT = 1 is more than a CU sustains
-    bool found = false;
-    double best = 0.0;
     static const double l2_factor[4] = {0.0, 1.6, 1.15, 1.0};
     static const int ipw_env = tune_int("DTO_SWEEP_IPW", 0);  // A/B runs (TUNING builds)
-    for (int ipw = 1; ipw <= 48; ++ipw) {
-        const int NC = T * ipw, NT = (NC + 15) / 16;
-        if (NT > 3) break;
-        if (ipw_env > 0 && ipw != ipw_env && T == 1 + m) continue;
-        const FusedLds L(npad, T, m, ipw, nslot, MT);
-        const size_t bytes = (size_t)L.total * sizeof(double);
-        if (bytes > 156 * 1024) break;
-        const long nblocks = (long)((n_int + ipw - 1) / ipw);
-        const long rounds = (nblocks + n_cu - 1) / n_cu;
-        // ties go to the fewer workgroups (less MFMA work issued in total)
-        const double cost = (double)rounds * NT * RB * l2_factor[NT] + 1e-6 * (double)nblocks * NT;
-        if (!found || cost < best) {
-            found = true; best = cost;
-            out.MT = MT; out.NT = NT; out.ipw = ipw; out.nslot = nslot; out.lds_bytes = bytes; out.nblocks = (int)nblocks;
+    auto search = [&](int WC) {
+        bool found = false;
+        double best = 0.0;
+        for (int ipw = 1; ipw <= 48; ++ipw) {
+            const int NC = T * ipw;
+            int NT = (NC + 15) / 16;
+            if (WC == 2) {
+                if (NT > 4) break;
+                if (NT != 4) continue;  // two column groups of two tiles each
+                NT = 2;
+            } else if (NT > 3) break;
+            if (ipw_env > 0 && ipw != ipw_env && T == 1 + m) continue;
+            const FusedLds L(npad, T, m, ipw, nslot, MT);
+            const size_t bytes = (size_t)L.total * sizeof(double);
+            if (bytes > 156 * 1024) break;
+            const long nblocks = (long)((n_int + ipw - 1) / ipw);
+            const long rounds = (nblocks + n_cu - 1) / n_cu;
+            // ties go to the fewer workgroups (less MFMA work issued in total)
+            const double cost = (double)rounds * NT * RB * l2_factor[NT] + 1e-6 * (double)nblocks * NT;
+            if (!found || cost < best) {
+                found = true; best = cost;
+                out.MT = MT; out.NT = NT; out.WC = WC; out.ipw = ipw; out.nslot = nslot; out.lds_bytes = bytes; out.nblocks = (int)nblocks;
+            }
         }
-    }
-    return found && 2 * out.nblocks >= n_cu;
+        return found && 2 * out.nblocks >= n_cu;
+    };
+    // Eight wavefronts in two column groups (256 states, 49..64 columns: 12 intervals of a Jacobian sweep per workgroup): two
+    // wavefronts per SIMD hide each other's operand traffic, +10 % MFMA rate per CU -- but a third fewer workgroups, each a
+    // fifth longer (256 x 2000: 167 workgroups, 4.0 ms against 223, 3.3 ms).  It pays when the CUs the sweep leaves free are
+    // used by another stream (`shared_chip`: the Jacobian's sweep next to the propagator chain), not when the sweep runs alone.
+    if (shared_chip && npad == 256 && search(2)) return true;
+    return search(1);
 }
 
 hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
@@ -509,6 +527,7 @@ hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, con
     a.G = transposed ? B.GT : B.G;
     a.Zsrc = dZ; a.mu = dmu; a.src_kind = src_kind;
     a.q = q; a.d_ub = d_ub; a.tc = tc; a.ipw = pl.ipw; a.store = store ? 1 : 0; a.nslot = pl.nslot; a.tol = tol;
+    if (pl.WC == 2 && pl.MT == 4 && pl.NT == 2) return launch_one<4, 2, 2>(st, a, pl.nblocks, pl.lds_bytes);
     const int key = pl.MT * 10 + pl.NT;
     switch (key) {
         case 41: return launch_one<4, 1>(st, a, pl.nblocks, pl.lds_bytes);

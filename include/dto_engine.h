@@ -272,7 +272,9 @@ int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const do
  *   before the first such call.
  *   "overlap_sweep" (default 1): eval_constraint_jacobian runs its generator sweep on a second stream next to the polynomial
  *   products and squarings of the propagator chain (5-6 % faster at 256 states x 2000 knots); 0 runs one kernel at a time,
- *   which is what per-kernel measurements (dto_profile_get, rocprofv3) need.  Results are bit-identical either way.
+ *   which is what per-kernel measurements (dto_profile_get, rocprofv3) need.  Results agree to rounding: bit-identical, except
+ *   that next to the chain a 256-state sweep over 1536 intervals or more groups its intervals by twelve instead of nine (a
+ *   different, equally fixed summation order of the generator products).
  *   "sweep_form" (default 0): 0 runs the generator sweep as one persistent launch where that form applies, 1 always one
  *   launch per Taylor step.
  *   "chain_chunk" (default 0 = the engine's workspace budget): at most this many intervals per chunk of the propagator

@@ -2,7 +2,7 @@
 // arguments directly (no engine), runs the Jacobian's forward sweep (T = 1 + m column types) and prints time, the
 // statistics [non-converged workgroups, max terms, sum of terms] and the implied MFMA rate.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I directtrajopt.jl_amd/csrc tools/sweep_fused_probe.hip -o tools/sweep_fused_probe [-DPROBE_...]
-// usage: sweep_fused_probe [n m N d_ub tc ipw_override]
+// usage: sweep_fused_probe [n m N d_ub tc ipw_override shared_chip]   (shared_chip = 1: the two-column-group form of 256 states)
 #include "dto_sweep_fused.hip"
 
 #include <cstdio>
@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     const int d_ub = argc > 4 ? atoi(argv[4]) : 30;
     const int tc_arg = argc > 5 ? atoi(argv[5]) : -1;
     const int ipw_over = argc > 6 ? atoi(argv[6]) : 0;
+    const bool shared = argc > 7 && atoi(argv[7]) != 0;
     const int npad = (n + 63) / 64 * 64, z = n + 2 * m + 1, K = N - 1;
     std::mt19937_64 rng(42);
     std::normal_distribution<double> nd;
@@ -53,13 +54,13 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&w.stats, 16));
     CK(sweep_fused_prepare());
     FusedSweepPlan pl{};
-    if (!sweep_fused_plan(npad, m, ty, K, 256, pl)) { printf("no plan\n"); return 1; }
+    if (!sweep_fused_plan(npad, m, ty, K, 256, pl, shared)) { printf("no plan\n"); return 1; }
     if (ipw_over > 0) {
-        pl.ipw = ipw_over; pl.NT = (ty.T * ipw_over + 15) / 16; pl.nblocks = (K + ipw_over - 1) / ipw_over;
+        pl.ipw = ipw_over; pl.NT = (ty.T * ipw_over + 15) / 16 / pl.WC; pl.nblocks = (K + ipw_over - 1) / ipw_over;
         pl.lds_bytes = (size_t)FusedLds(npad, ty.T, m, ipw_over, pl.nslot, pl.MT).total * 8;
     }
     const int tc = tc_arg >= 0 ? tc_arg : d_ub / 2 - 1;
-    printf("n=%d m=%d N=%d npad=%d  plan: MT=%d NT=%d ipw=%d blocks=%d lds=%zu  d_ub=%d tc=%d\n", n, m, N, npad, pl.MT, pl.NT, pl.ipw,
+    printf("n=%d m=%d N=%d npad=%d  plan: WC=%d MT=%d NT=%d ipw=%d blocks=%d lds=%zu  d_ub=%d tc=%d\n", n, m, N, npad, pl.WC, pl.MT, pl.NT, pl.ipw,
            pl.nblocks, pl.lds_bytes, d_ub, tc);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -75,7 +76,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(st, w.stats, 16, hipMemcpyDeviceToHost));
         const double mean_terms = (double)st[2] / pl.nblocks;
         const double flops_useful = 2.0 * npad * npad * (m + 1) * (double)ty.T * K * (mean_terms - 1);
-        const double flops_issued = 2.0 * npad * npad * (m + 1) * 16.0 * pl.NT * pl.nblocks * (mean_terms - 1);
+        const double flops_issued = 2.0 * npad * npad * (m + 1) * 16.0 * pl.NT * pl.WC * pl.nblocks * (mean_terms - 1);
         if (rep >= 3)
             printf("  %.3f ms  nonconv=%d max_terms=%d mean_terms=%.2f  useful %.1f TF/s, issued %.1f TF/s\n", ms, st[0], st[1],
                    mean_terms, flops_useful / ms * 1e-9, flops_issued / ms * 1e-9);
