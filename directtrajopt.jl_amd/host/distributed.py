@@ -43,22 +43,61 @@ def slab_layout(lo, n, group=None):
     return pairs
 
 
-def gather_slabs_inplace(full, layout, group=None):
+def padded_gather_plan(layout):
+    """One equal-size all-gather moves knot-range slabs IN PLACE if the vector is allocated with a little padding: the slabs
+    of the interior ranks are equally long (n) and back to back, only the first and the last are shorter (knot 1 has no
+    z_{k+1} half, knot N no own half).  With n - n_first doubles in front and n - n_last behind, rank r's slab lies inside
+    chunk r of a buffer of world * n doubles (at the chunk's end for rank 0, at its start for the others).
+    Returns (n, pad_front, pad_back) or None when the layout does not have that shape."""
+    world = len(layout)
+    n = max(ln for _, ln in layout)
+    lo0, n0 = layout[0]
+    if n == 0:
+        return None
+    for r in range(1, world):
+        lo, ln = layout[r]
+        if lo != lo0 + n0 + (r - 1) * n or ln > n or (r < world - 1 and ln != n):
+            return None
+    return n, n - n0, n - layout[-1][1]
+
+
+def alloc_gather_vector(total, layout, dtype, device):
+    """(buffer, full): `full` is the value vector of `total` entries every rank's engine writes its slab into
+    (full[lo_r : lo_r + n_r]); `buffer` is the padded allocation behind it that `gather_slabs_inplace` hands to the
+    equal-size all-gather (None when the layout needs the per-rank broadcasts)."""
+    import torch
+    plan = padded_gather_plan(layout)
+    if plan is None or sum(ln for _, ln in layout) != total or layout[0][0] != 0:
+        return None, torch.empty(total, dtype=dtype, device=device)
+    n, front, back = plan
+    buf = torch.empty(front + total + back, dtype=dtype, device=device)
+    buf[:front].zero_()
+    buf[front + total:].zero_()
+    return buf, buf[front:front + total]
+
+
+def gather_slabs_inplace(full, layout, group=None, buffer=None):
     """All-gather of knot-range slabs WITHOUT staging copies: `full` is the whole value vector (allocated on every rank),
     rank r's engine has written its slab straight into full[lo_r : lo_r + n_r] (the `*_dev` entry points take the slice's
     pointer), and this call fills in the other ranks' slices.
 
-    Equal slab lengths (and slabs laid out back to back) go through ONE all_gather_into_tensor on the vector itself; the
-    general case (first and last rank own one boundary column block more or less) is one in-place broadcast per rank --
-    the same bytes over the same links as a ring all-gather, no padding, no concatenation.  Backend "nccl" is RCCL over
-    xGMI on the GPU box; "gloo" serves the CPU and one-device rehearsals."""
+    With the padded allocation of `alloc_gather_vector` (`buffer`) that is ONE all_gather_into_tensor on the buffer itself --
+    every link busy at once, the 2.2 GB slabs of configs[3] never copied.  Without it: the same single call when the slabs
+    happen to be equal and back to back, else one in-place broadcast per rank (same bytes, but one source at a time).
+    Backend "nccl" is RCCL over xGMI on the GPU box; "gloo" serves the CPU and one-device rehearsals."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     assert len(layout) == world
+    one_call = dist.get_backend(group) == "nccl" or not full.is_cuda
+    if buffer is not None and one_call:
+        n, front, back = padded_gather_plan(layout)
+        assert buffer.numel() == world * n and full.data_ptr() == buffer.data_ptr() + front * buffer.element_size()
+        dist.all_gather_into_tensor(buffer, buffer[rank * n:(rank + 1) * n], group=group)
+        return full
     lens = {n for _, n in layout}
     contiguous = all(layout[r][0] == layout[0][0] + r * layout[0][1] for r in range(world))
-    if len(lens) == 1 and contiguous and (dist.get_backend(group) == "nccl" or not full.is_cuda):
+    if len(lens) == 1 and contiguous and one_call:
         lo0, n = layout[0]
         dist.all_gather_into_tensor(full[lo0:lo0 + world * n], full[layout[rank][0]:layout[rank][0] + n], group=group)
         return full

@@ -53,6 +53,14 @@ def _worker(rank, world, port, q):
             assert layout[rank] == (a, n) and sum(x[1] for x in layout) == full[key].size
             dto_amd.distributed.gather_slabs_inplace(vec, layout)
             ok &= bool(np.array_equal(vec.numpy(), full[key]))
+            # ... and on the padded allocation, where ONE equal-size all-gather moves the unequal slabs in place
+            buf, vec2 = dto_amd.distributed.alloc_gather_vector(full[key].size, layout, torch.float64, "cpu")
+            if key in ("jac", "hess"):
+                ok &= buf is not None and buf.numel() == world * max(x[1] for x in layout)
+            vec2.fill_(float("nan"))
+            vec2[a:a + n] = local
+            dto_amd.distributed.gather_slabs_inplace(vec2, layout, buffer=buf)
+            ok &= bool(np.array_equal(vec2.numpy(), full[key]))
         # constraint rows: scatter the local buffer back through the row segments, then sum over ranks
         st, ln = ev.shard_rows()
         g = torch.zeros(ev.n_constraints, dtype=torch.float64)
@@ -72,8 +80,20 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_shards_and_gather():
-    world = 2
+def test_padded_gather_plan_shapes():
+    P = dto_amd.distributed.padded_gather_plan
+    assert P([(0, 7), (7, 10), (17, 10), (27, 6)]) == (10, 3, 4)       # first and last rank one boundary half-block short
+    assert P([(0, 5), (5, 8)]) == (8, 3, 0) and P([(0, 8), (8, 8)]) == (8, 0, 0)
+    assert P([(0, 7), (7, 10), (17, 9), (26, 6)]) is None              # an interior rank that is shorter
+    assert P([(0, 7), (8, 10), (18, 10)]) is None                      # a gap
+    assert P([(0, 0), (0, 0)]) is None
+
+
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_shards_and_gather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -83,4 +103,4 @@ def test_two_rank_shards_and_gather():
     res = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
