@@ -480,10 +480,13 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
                 if (ty.t[t].gen[x] == g) mask |= 1 << ty.t[t].src[x];
         nslot = nslot > __builtin_popcount(mask) ? nslot : __builtin_popcount(mask);
     }
-    const int RB = 1;
-    // cost model: one workgroup per CU and round; a round takes NT * RB units of MFMA time, and a narrow column tile
-    // streams the generators from L2 at 512 / (16 NT) bytes per cycle and CU, which at NT = 1 is more than a CU sustains
+    // cost model, 256 states: one workgroup per CU and round; a round takes NT units of MFMA time, and a narrow column tile
+    // streams the generators from L2 at 512 / (16 NT) bytes per cycle and CU, which at NT = 1 is more than a CU sustains.
+    // 64 and 128 states: the steps are latency-bound (two barriers and an epilogue per handful of MFMAs), several workgroups
+    // share a CU, and one column tile per workgroup is fastest -- measured per sweep at 1000 knots, NT = 1 / 2 / 3:
+    // 0.24 / 0.30 / 0.44 ms (64 states), 0.61 / 0.73 / 0.86 ms (128 states); three workgroups per CU count as one round.
     static const double l2_factor[4] = {0.0, 1.6, 1.15, 1.0};
+    static const double t_small[2][4] = {{0.0, 0.24, 0.30, 0.44}, {0.0, 0.61, 0.73, 0.86}};
     static const int ipw_env = tune_int("DTO_SWEEP_IPW", 0);  // A/B runs (TUNING builds)
     auto search = [&](int WC) {
         bool found = false;
@@ -501,9 +504,10 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
             const size_t bytes = (size_t)L.total * sizeof(double);
             if (bytes > 156 * 1024) break;
             const long nblocks = (long)((n_int + ipw - 1) / ipw);
-            const long rounds = (nblocks + n_cu - 1) / n_cu;
+            const long slots = MT <= 2 ? 3L * n_cu : n_cu;
+            const long rounds = (nblocks + slots - 1) / slots;
             // ties go to the fewer workgroups (less MFMA work issued in total)
-            const double cost = (double)rounds * NT * RB * l2_factor[NT] + 1e-6 * (double)nblocks * NT;
+            const double cost = (MT <= 2 ? (double)rounds * t_small[MT - 1][NT] : (double)rounds * NT * l2_factor[NT]) + 1e-6 * (double)nblocks * NT;
             if (!found || cost < best) {
                 found = true; best = cost;
                 out.MT = MT; out.NT = NT; out.WC = WC; out.ipw = ipw; out.nslot = nslot; out.lds_bytes = bytes; out.nblocks = (int)nblocks;

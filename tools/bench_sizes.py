@@ -1,5 +1,5 @@
 """Callback times at other shapes than the headline's, with the fused sweep and the step-per-launch sweep (option sweep_form)
-side by side.  usage: python tools/bench_sizes.py [--big]"""
+side by side.  usage: python tools/bench_sizes.py [--big] [--tdb-only] [--host-mirror]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, dto_amd
@@ -58,8 +58,8 @@ def run_tdb(n, m, N, order=1, substeps=32, steps=3):
                                       [("cos", 1.7, 0.5 * rng.standard_normal((m + 1, n, n)) / np.sqrt(n))])
     Z = traj.vec()
     for on_device in (True, False):
-        if not on_device and n * N > 400:
-            continue  # the host mirror needs minutes there (93 s for ONE Hessian at n = 4, N = 100)
+        if not on_device and (n * N > 400 or "--host-mirror" not in sys.argv):
+            continue  # the host mirror needs 93 s for ONE Hessian at n = 4, N = 100: only on request
         tdb = dto_amd.TimeDependentBilinearIntegrator(fam, "x", "u", "t", traj, spline_order=order, substeps=substeps, on_device=on_device)
         ev = dto_amd.Evaluator(dto_amd.DirectTrajOptProblem(traj, dto_amd.QuadraticRegularizer("u", traj, 1.0), [tdb]))
         mu = np.ones(ev.n_constraints)
