@@ -389,3 +389,36 @@ def test_sweep_on_the_second_stream_changes_no_bit():
         outs.append(o.cpu().numpy())
     ev.close()
     assert np.isfinite(outs[0]).all() and rel_err(outs[0], outs[1]) <= 1e-12
+
+
+def test_host_pointer_calls_back_to_back_match_the_device_resident_ones():
+    """The host-pointer Jacobian hands its -E_k blocks to a drainer thread chain chunk by chain chunk while the GPU still
+    computes (dto_hostxfer.h), host threads scatter into the caller's vector.  Twelve calls in a row at changing points,
+    Jacobian and Hessian alternating, each into a buffer full of NaN: every result must equal the device-resident entry
+    point's, bit for bit (Jacobian; same kernels) / to rounding (Hessian: floating-point atomics)."""
+    import torch
+    import dto_amd
+    dev = torch.device("cuda", 0)
+    p = O.make_scaled_problem(700, 64, 3, seed=17)
+    ev = dto_amd.Evaluator(to_engine(p))
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(9)
+    mu = rng.standard_normal(ev.n_constraints)
+    mu_d = torch.from_numpy(mu).to(dev)
+    jd = torch.empty(ev.shard.jac_len, dtype=torch.float64, device=dev)
+    hd = torch.empty(ev.shard.hess_len, dtype=torch.float64, device=dev)
+    for it in range(12):
+        Z = p.Z0 + 0.01 * rng.standard_normal(p.Z0.size)
+        Zd = torch.from_numpy(Z).to(dev)
+        j = np.full(ev.shard.jac_len, np.nan)
+        ev.eval_constraint_jacobian(j, Z)
+        ev.eval_jacobian_dev(Zd.data_ptr(), jd.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(j, jd.cpu().numpy()), it
+        if it % 2 == 0:
+            h = np.full(ev.shard.hess_len, np.nan)
+            ev.eval_hessian_lagrangian(h, Z, 0.5, mu)
+            ev.eval_hessian_dev(Zd.data_ptr(), 0.5, mu_d.data_ptr(), hd.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert rel_err(h, hd.cpu().numpy()) <= 1e-12, it
+    ev.close()
