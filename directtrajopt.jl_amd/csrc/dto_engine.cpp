@@ -1008,7 +1008,9 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
             // products and squarings of the chain: its 223 workgroups leave 33 CUs idle and every chain launch has a tail --
             // together 5-6 % of the call (12.3 -> 11.5 ms at 256 x 2000).  Option "overlap_sweep" = 0 runs one kernel at a
             // time (per-kernel timings mean something only then).
-            const bool overlap = h->overlap_sweep != 0;
+            // (from 512 states on the step-per-launch sweep's small launches only get in the way of the chain's big ones:
+            // 18.7 -> 19.3 ms at 512 x 500, 71.1 -> 72.5 ms at 1024 x 300; below, 3-6 % faster: tools/overlap_by_size.py)
+            const bool overlap = h->overlap_sweep != 0 && b.k.npad < 512;
             hipStream_t ss = overlap ? h->stream2 : st;
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
