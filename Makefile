@@ -23,11 +23,14 @@ $(CSRC)/dto_sweep_fused.o: $(CSRC)/dto_sweep_fused.hip $(CSRC)/dto_kernels.h $(C
 $(CSRC)/dto_hostxfer.o: $(CSRC)/dto_hostxfer.cpp $(CSRC)/dto_hostxfer.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(CSRC)/dto_engine.o: $(CSRC)/dto_engine.cpp $(CSRC)/dto_kernels.h $(CSRC)/dto_hostxfer.h include/dto_engine.h
+$(CSRC)/dto_comm.o: $(CSRC)/dto_comm.cpp $(CSRC)/dto_comm.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_small.o $(CSRC)/dto_sweep_fused.o $(CSRC)/dto_tdb.o $(CSRC)/dto_hostxfer.o $(CSRC)/dto_engine.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+$(CSRC)/dto_engine.o: $(CSRC)/dto_engine.cpp $(CSRC)/dto_kernels.h $(CSRC)/dto_hostxfer.h $(CSRC)/dto_comm.h include/dto_engine.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(CSRC)/dto_kernels.o $(CSRC)/dto_small.o $(CSRC)/dto_sweep_fused.o $(CSRC)/dto_tdb.o $(CSRC)/dto_hostxfer.o $(CSRC)/dto_comm.o $(CSRC)/dto_engine.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread -ldl
 
 clean:
 	rm -f $(CSRC)/*.o $(LIB)

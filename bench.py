@@ -6,7 +6,10 @@ benchmark/problem_utils.jl:49-77, callback src/solvers/evaluator.jl:368-380).
 A "step" is one eval_constraint_jacobian call over the whole (per-GPU) trajectory with Z and the
 value vector resident in HBM.  With --gpus N each rank owns a contiguous knot range of an
 N*2000-knot problem (weak scaling, no data-path collective: every rank's output is one contiguous
-slab of the CSC value vector).
+slab of the CSC value vector); `--scaling strong` splits the 2000 knots of the metric
+itself over the N ranks instead, and the weak line carries that measurement as its `strong_scaling`
+block.  Started WITHOUT torchrun, `--gpus N` launches its N ranks itself (a child
+`python -m torch.distributed.run`, before this process touches a GPU) and relays their line.
 
 Prints ONE JSON line on rank 0."""
 import argparse
@@ -30,6 +33,30 @@ def baseline_metric():
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
         return "knot-points/sec for eval_constraint_jacobian, 256-state\u00d72000-knot bilinear"
+
+
+def spawn_ranks(n_ranks, argv):
+    """`bench.py --gpus N` started by hand or by a driver that does not use torchrun: launch the N ranks as a child
+    `python -m torch.distributed.run` and relay their output.  Runs before this process has made any GPU call (counting
+    devices does not initialise the runtime on this image); the parent never touches the GPU and exits with the child's code."""
+    import socket
+    import subprocess
+    if "--one-device" not in argv:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n_ranks:
+            raise SystemExit(f"bench.py --gpus {n_ranks}: only {have} GPU(s) visible -- refusing to measure fewer devices than asked for "
+                             f"(--one-device with --backend gloo rehearses the multi-rank path on one GPU)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # torch.distributed.run's own parser claims --n: hand the state dimension over under its long name
+    argv = ["--states" if a == "--n" else a for a in argv]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _run_workers(cmds, env=None, timeout=600):
@@ -132,63 +159,79 @@ def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
     return out
 
 
-def measure_gather(args, dto_amd, torch, dist, ev, prob, dev, Z, stream, fence, N_total, mu):
-    """configs[3]'s data path: every rank holds the WHOLE value vector; its engine writes the rank's slab straight into its
-    slice, the other slices arrive by the in-place all-gather (dto_amd.distributed.gather_slabs_inplace: RCCL over xGMI
-    with backend nccl; no padded copy, no concatenation).  Times K steps of callback + gather and K gathers alone."""
-    sh = ev.shard
-    lo, ln = (sh.jac_lo, sh.jac_len) if args.callback == "jacobian" else (sh.hess_lo, sh.hess_len)
-    total = ev.n_jacobian_entries if args.callback == "jacobian" else ev.n_hessian_entries
-    layout = dto_amd.distributed.slab_layout(lo, ln)
-    # padded allocation: the first and the last rank's slabs are one boundary half-block shorter than the others; with that
-    # much padding in front and behind, ONE equal-size all-gather moves every slab in place (host/distributed.py)
-    gbuf, full = dto_amd.distributed.alloc_gather_vector(total, layout, torch.float64, dev)
-    mine = full[lo:lo + ln]
+def exchange_comm_id(dto_amd, dist, rank):
+    """The 128 bytes of ncclGetUniqueId from rank 0 to every rank (torch.distributed is plumbing here; any transport does)."""
+    box = [dto_amd.Evaluator.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def measure_gather(args, dto_amd, torch, dist, ev, prob, dev, Z, stream, fence, N_total, mu, rank, world):
+    """configs[3]'s data path through the ENGINE's collectives (C ABI, include/dto_engine.h "Multi-GPU"; RCCL over xGMI):
+    every rank allocates the whole value vector with the padding dto_get_gather_layout prescribes, its engine writes the rank's
+    slab straight into its slice, dto_gather_*_dev fills in the others with ONE in-place ncclAllGather.  Times K steps of
+    callback + gather and K gathers alone; then the overlapped form (the rank's knots over two handles with a communicator
+    each: the first half's slabs travel on a second stream while the second half computes)."""
+    capi = dto_amd.capi
+    vec = capi.VECTOR_JACOBIAN if args.callback == "jacobian" else capi.VECTOR_HESSIAN
+    ev.comm_create(exchange_comm_id(dto_amd, dist, rank), rank, world)
+    L = ev.gather_layout(vec)
+    gbuf = torch.empty(L.padded_len, dtype=torch.float64, device=dev)
+    gbuf[:L.front_pad].zero_()
+    gbuf[L.front_pad + L.total:].zero_()
+    full = gbuf[L.front_pad:L.front_pad + L.total]
+    mine = full[L.own_lo:L.own_lo + L.own_len]
+    total, ln = L.total, L.own_len
     if args.callback == "jacobian":
         gstep = lambda: ev.eval_jacobian_dev(Z.data_ptr(), mine.data_ptr(), stream)
     else:
         gstep = lambda: ev.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), mine.data_ptr(), stream)
+    gather = lambda: ev.gather_dev(vec, gbuf.data_ptr(), stream)
     for _ in range(max(1, args.warmup)):
         gstep()
-        dto_amd.distributed.gather_slabs_inplace(full, layout, buffer=gbuf)
+        gather()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gstep()
-        dto_amd.distributed.gather_slabs_inplace(full, layout, buffer=gbuf)
+        gather()
     fence()
     t_both = time.perf_counter() - t0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dto_amd.distributed.gather_slabs_inplace(full, layout, buffer=gbuf)
+        gather()
     fence()
     t_gather = time.perf_counter() - t0
-    # Overlapped form: the rank's knots over two engine handles; while the second half computes, the first half's slabs are
-    # already on the links (asynchronous in-place broadcasts on the backend's stream).  Same collectives in the same order
-    # on every rank.
     t_over, over_diff, over_err = float("nan"), None, None
     try:
         D = dto_amd.distributed
-        k_lo, k_hi = ev.shard.k_lo, ev.shard.k_hi
         subs = []
-        for a, b in D.split_range(k_lo, k_hi, 2):
+        for a, b in D.split_range(ev.shard.k_lo, ev.shard.k_hi, 2):
             e = dto_amd.Evaluator(prob, eval_hessian=(args.callback == "hessian"), device=dev.index, k_lo=a, k_hi=b)
-            slo, sln = (e.shard.jac_lo, e.shard.jac_len) if args.callback == "jacobian" else (e.shard.hess_lo, e.shard.hess_len)
-            subs.append((e, slo, sln, D.slab_layout(slo, sln)))
+            e.comm_create(exchange_comm_id(dto_amd, dist, rank), rank, world)
+            subs.append((e, e.gather_layout(vec)))
         stride = max(1, total // 65536)
         want = full[::stride].clone()
+        side = torch.cuda.Stream(device=dev)
+        main_stream = torch.cuda.current_stream(dev)
 
         def ostep():
-            works = []
-            for e, slo, sln, lay in subs:
-                dst = full[slo:slo + sln]
+            evs = []
+            for e, Ls in subs:
+                dst = full.data_ptr() + 8 * Ls.own_lo
                 if args.callback == "jacobian":
-                    e.eval_jacobian_dev(Z.data_ptr(), dst.data_ptr(), stream)
+                    e.eval_jacobian_dev(Z.data_ptr(), dst, stream)
                 else:
-                    e.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), dst.data_ptr(), stream)
-                works += D.gather_slabs_async(full, lay)
-            for w in works:
-                w.wait()
+                    e.eval_hessian_dev(Z.data_ptr(), 1.0, mu.data_ptr(), dst, stream)
+                done = torch.cuda.Event()
+                done.record(main_stream)
+                side.wait_event(done)               # the gather of this handle's slabs follows ITS callback only
+                e.gather_dev(vec, full.data_ptr(), side.cuda_stream)
+                g = torch.cuda.Event()
+                g.record(side)
+                evs.append(g)
+            for g in evs:
+                main_stream.wait_event(g)
         full.zero_()
         for _ in range(max(1, args.warmup)):
             ostep()
@@ -200,7 +243,8 @@ def measure_gather(args, dto_amd, torch, dist, ev, prob, dev, Z, stream, fence, 
             ostep()
         fence()
         t_over = time.perf_counter() - t0
-        for e, *_ in subs:
+        for e, _ in subs:
+            e.comm_destroy()
             e.close()
     except Exception as e:  # reported, never fatal
         over_err = repr(e)
@@ -208,20 +252,51 @@ def measure_gather(args, dto_amd, torch, dist, ev, prob, dev, Z, stream, fence, 
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t_both, t_gather, t_over = (float(x) for x in tt.tolist())
     chk = bool(torch.isfinite(full[::max(1, total // 4096)]).all().item())
-    res = {"n_ranks": dist.get_world_size(), "backend": args.backend, "bytes_per_rank_vector": 8.0 * total,
-           "collective": ("one in-place all_gather_into_tensor on the padded vector" if gbuf is not None and (args.backend == "nccl" or not full.is_cuda)
-                          else "one in-place broadcast per rank"),
+    res = {"n_ranks": L.world, "transport": "RCCL through the engine's C ABI (dto_comm_create / dto_gather_%s_dev)" % args.callback,
+           "bytes_per_rank_vector": 8.0 * total,
+           "collective": ("one in-place ncclAllGather on the padded vector" if L.in_place_all_gather else "one in-place ncclBroadcast per rank (grouped)"),
            "ms_per_step_compute_and_gather": t_both / args.steps * 1e3, "gather_ms": t_gather / args.steps * 1e3,
            "gather_gbs_per_rank_received": 8.0 * (total - ln) / (t_gather / args.steps) / 1e9,
            "knot_points_per_s_with_gather": N_total * args.steps / t_both, "sampled_finite": chk,
            "overlap": "ms_per_step_compute_and_gather: none, the gather follows the callback; ms_per_step_overlapped: each rank's "
                       "knots over two handles, the first half's slabs travel while the second half computes (DESIGN.md section 6)"}
+    if args.one_device:
+        res["wire"] = "rehearsal on one device: the ranks pose as separate hosts (NCCL_HOSTID) and RCCL uses its socket transport"
     if t_over == t_over:
         res.update({"ms_per_step_overlapped": t_over / args.steps * 1e3, "knot_points_per_s_overlapped": N_total * args.steps / t_over,
                     "overlapped_vs_sequential_max_rel_diff_sampled": over_diff})
     if over_err:
         res["overlapped_error"] = over_err
+    ev.comm_destroy()
     return res, mine
+
+
+def measure_strong(args, dto_amd, torch, dist, dev, rank, world, fence, n, m):
+    """The literal BASELINE metric at N GPUs: the `--knots`-knot problem itself split over the ranks (strong scaling)."""
+    Nk = args.knots
+    prob = dto_amd.host.synthetic.make_scaled_problem(Nk, n, m, seed=42)
+    lo, hi = dto_amd.distributed.shard_ranges(Nk, world)[rank]
+    ev = dto_amd.Evaluator(prob, eval_hessian=False, device=dev.index, k_lo=lo, k_hi=hi)
+    try:
+        Z = torch.from_numpy(prob.trajectory.vec()).to(dev)
+        out = torch.empty(ev.shard.jac_len, dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        step = lambda: ev.eval_jacobian_dev(Z.data_ptr(), out.data_ptr(), stream)
+        for _ in range(max(1, args.warmup)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        return {"scaling": "strong", "knots_total": Nk, "knots_per_gpu": hi - lo + 1, "ms_per_step": el / args.steps * 1e3,
+                "value": Nk * args.steps / el, "unit": "knot-points/s",
+                "outputs_finite": bool(torch.isfinite(out[::max(1, out.numel() // 4096)]).all().item())}
+    finally:
+        ev.close()
 
 
 def main():
@@ -249,17 +324,33 @@ def main():
                          "written into the full value vector and all-gathered in place (RCCL over xGMI); reported next to `value`. "
                          "On by default when there is more than one rank")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --knots per GPU (configs[3] at 8 GPUs: 16000 knots); strong: --knots in total, split over the GPUs "
+                         "(the metric's own 2000-knot problem at 1, 2, 4, 8 GPUs).  The weak line also carries the strong "
+                         "measurement as its `strong_scaling` block")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: start the ranks ourselves, BEFORE this process makes any GPU call, and relay their line
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_device and world > 1:
+        # one device, several RCCL ranks (rehearsal): every rank poses as a host of its own, RCCL then takes its socket
+        # transport over loopback instead of refusing the duplicate device.  Must be in place before RCCL is loaded.
+        os.environ["NCCL_HOSTID"] = f"dto-bench-rank-{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
     import numpy as np
     import torch
     import dto_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not args.one_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     dist = None
     if args.one_device:
         local_rank = 0
@@ -275,9 +366,12 @@ def main():
     torch.cuda.set_device(dev)
 
     n, m, Nk = args.n, args.m, args.knots
-    N_total = Nk * world
+    strong = args.scaling == "strong"
+    N_total = Nk if strong else Nk * world
     prob = dto_amd.host.synthetic.make_scaled_problem(N_total, n, m, seed=42)
-    k_lo, k_hi = rank * Nk + 1, (rank + 1) * Nk
+    k_lo, k_hi = dto_amd.distributed.shard_ranges(N_total, world)[rank]
+    if strong:
+        Nk = k_hi - k_lo + 1   # this rank's share (the per-kernel accounting below is per rank)
     ev = dto_amd.Evaluator(prob, eval_hessian=(args.callback == "hessian"), device=local_rank, k_lo=k_lo, k_hi=k_hi)
     Z = torch.from_numpy(prob.trajectory.vec()).to(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -372,13 +466,33 @@ def main():
         del out  # its place is taken by the rank's slice of the full vector
         try:
             gather, out = measure_gather(args, dto_amd, torch, dist, ev, prob, dev, Z, stream, fence, N_total,
-                                         mu if args.callback == "hessian" else None)
+                                         mu if args.callback == "hessian" else None, rank, world)
         except Exception as e:  # the gather is a report next to `value`, never a reason to lose the line
             gather, out = {"error": repr(e)}, torch.empty(n_out, dtype=torch.float64, device=dev)
 
+    # the metric's own problem split over the ranks, next to the weak-scaling `value` (all ranks take part)
+    strong_block = None
+    if dist is not None and not strong and args.callback == "jacobian":
+        try:
+            strong_block = measure_strong(args, dto_amd, torch, dist, dev, rank, world, fence, n, m)
+        except Exception as e:
+            strong_block = {"error": repr(e)}
+
+    # per-step times, each step fenced on its own: the median next to the mean that `value` is (SURVEY.md §8d quotes a median)
+    step_ms = []
+    if args.callback == "jacobian" and world == 1:
+        ostep = (lambda: ev.eval_jacobian_dev(Z.data_ptr(), out.data_ptr(), stream))
+        for _ in range(args.steps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ostep()
+            torch.cuda.synchronize(dev)
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_k_bgemm.json")))
+        import glob
+        tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_traffic*.json")))[-1]))  # the latest round's
         if (n, Nk, args.callback) == (256, 2000, "jacobian"):
             traffic, traffic_src = tj["avg_per_launch_bytes"], tj["source"]
             pl = tj["per_launch_bytes"]
@@ -393,8 +507,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         achieved = fl_gemm / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
         line = {
-            "metric": baseline_metric() if (args.callback, n, Nk) == ("jacobian", 256, 2000)
-            else f"knot-points/sec for eval_{args.callback}, {n}-state x {Nk}-knot bilinear",
+            "metric": baseline_metric() if (args.callback, n, args.knots) == ("jacobian", 256, 2000)
+            else f"knot-points/sec for eval_{args.callback}, {n}-state x {args.knots}-knot bilinear",
             "value": N_total * args.steps / elapsed,
             "unit": "knot-points/s",
             "n_gpus": world,
@@ -402,15 +516,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {n}-state bilinear, {m} drives, N={Nk} knots per GPU "
+            "config": {"workload": (f"configs[2]: {n}-state bilinear, {m} drives, N={N_total} knots split over {world} GPU(s) " if strong else
+                                    f"configs[2]: {n}-state bilinear, {m} drives, N={Nk} knots per GPU ") +
                                    f"(make_scaled_problem shape, Philox seed 42), callback={args.callback}",
                        "state_dim": n, "drives": m, "knots_per_gpu": Nk, "knots_total": N_total,
                        "parallelism": f"knot-range shards x{world}", "outputs_finite": finite,
-                       "max_squarings": smax, "sweep_terms": terms},
+                       "max_squarings": smax, "sweep_terms": terms,
+                       "inputs": "Z and the value slab resident in HBM; the 4.2 MB host-to-device copy of Z that SURVEY.md §8d's "
+                                 "metric lists is NOT in `value` (host-pointer figures: DESIGN.md §5)"},
             "roofline": {
                 "bound": "mfma", "kernel": "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -440,8 +557,14 @@ def main():
                 (2.0 * (-(-n // 64) * 64) ** 2 * (-(-(Nk - 1) // 128) * 128) * (m + 1) * (m + 1) * terms * args.steps)
                 if args.callback == "jacobian" else fl_sweep),
         }
+        if step_ms:
+            ss = sorted(step_ms)
+            line["ms_per_step_median"] = ss[len(ss) // 2] if len(ss) % 2 else 0.5 * (ss[len(ss) // 2 - 1] + ss[len(ss) // 2])
+            line["value_from_median"] = N_total / (line["ms_per_step_median"] * 1e-3)
         if gather is not None:
             line["gather"] = gather
+        if strong_block is not None:
+            line["strong_scaling"] = strong_block
         if world == 1 and args.callback == "jacobian" and not args.no_other_callbacks:
             # the other callbacks of the same problem, same protocol (3 untimed + 5 timed calls each): reported for
             # context (SURVEY.md §8d lists them next to the headline), never part of `value`

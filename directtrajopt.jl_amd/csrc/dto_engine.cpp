@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "dto_comm.h"
 #include "dto_hostxfer.h"
 #include "dto_kernels.h"
 
@@ -222,6 +223,16 @@ struct dto_handle {
     bool stats_pending = false;
     int32_t* h_stats = nullptr;  // pinned [2 * bilinear integrators][2]
     int last_form = 0;
+    // multi-GPU (dto_comm.h): the knot ranges of the communicator's ranks (dto_comm_create exchanges them over RCCL,
+    // dto_comm_set_ranges takes them from a caller with a transport of its own), the gather plans that follow from them,
+    // and the communicator itself
+    std::unique_ptr<Comm> comm;
+    int comm_rank = -1;
+    std::vector<std::pair<int64_t, int64_t>> rank_ranges;               // (k_lo, k_hi) per rank, 1-based inclusive
+    GatherPlan gather_plan[4];                                           // DTO_VECTOR_* - 1
+    std::vector<Slab> cons_segments;                                     // every rank's row segments of g ...
+    std::vector<int> cons_segment_root;                                  // ... and the rank that owns each
+    int64_t* d_ranges = nullptr;
     std::vector<void*> owned;  // device allocations to free
 
     ~dto_handle();
@@ -230,6 +241,7 @@ struct dto_handle {
 dto_handle::~dto_handle() {
     if (structure_only) return;
     (void)hipSetDevice(device);
+    comm.reset();
     for (auto& r : prof) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -384,6 +396,47 @@ inline size_t con_lower(const dto_handle* h, int64_t c) {
 int64_t hess_block_start(const dto_handle* h, int64_t kn) {
     const int64_t z = h->z, tri = z * (z + 1) / 2;
     return kn == 0 ? 0 : tri + (kn - 1) * (z * z + tri);
+}
+
+// value slabs of the handle that owns knots k_lo..k_hi (1-based, inclusive): positions inside the global vectors
+struct ShardExtents {
+    int64_t grad_lo, grad_len, jac_lo, jac_len, hess_lo, hess_len;
+};
+ShardExtents shard_extents(const dto_handle* h, int64_t k_lo, int64_t k_hi) {
+    const int64_t kn_lo = k_lo - 1, n_knots = k_hi - k_lo + 1;
+    const int64_t c_lo = kn_lo * h->z, c_hi = (kn_lo + n_knots) * h->z;
+    const bool last = k_hi == h->N;  // global-variable columns and the Hessian's tail ride with the last knot
+    ShardExtents e;
+    e.grad_lo = c_lo;
+    e.grad_len = c_hi - c_lo + (last ? h->gd : 0);
+    e.jac_lo = h->colptr[c_lo];
+    e.jac_len = h->colptr[last ? h->n_vars : c_hi] - e.jac_lo;
+    e.hess_lo = hess_block_start(h, kn_lo);
+    e.hess_len = hess_block_start(h, kn_lo + n_knots) - e.hess_lo + (last ? (int64_t)h->tail_rows.size() : 0);
+    return e;
+}
+
+// rows of g that handle owns, as (global 0-based start, length) segments in the order of its local buffer: per integrator the
+// rows of the owned intervals, then per constraint the listed times at owned knots (runs of consecutive listings merged)
+std::vector<std::pair<int64_t, int64_t>> shard_row_segments(const dto_handle* h, int64_t k_lo, int64_t k_hi) {
+    const int64_t kn_lo = k_lo - 1, n_knots = k_hi - k_lo + 1;
+    const int64_t n_int = std::max<int64_t>(0, std::min<int64_t>(k_hi, h->K) - k_lo + 1);
+    std::vector<std::pair<int64_t, int64_t>> seg;
+    for (size_t i = 0; i < h->integ_kind.size(); ++i)
+        if (n_int > 0) seg.emplace_back(h->integ_row_off[i] + kn_lo * h->integ_dim[i], n_int * h->integ_dim[i]);
+    for (auto& c : h->con) {
+        int64_t prev = -2;  // index of the previous owned listing of THIS constraint
+        for (int64_t i = 0; i < c.n_times_total; ++i) {
+            const int64_t kn = c.times0[i];
+            if (kn >= h->N ? k_hi != h->N : (kn < kn_lo || kn >= kn_lo + n_knots)) continue;  // pseudo-knot N: last rank
+            if (!seg.empty() && prev == i - 1 && seg.back().first + seg.back().second == c.row_off + i * c.g_dim)
+                seg.back().second += c.g_dim;
+            else
+                seg.emplace_back(c.row_off + i * c.g_dim, c.g_dim);
+            prev = i;
+        }
+    }
+    return seg;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1410,6 +1463,76 @@ int guarded(dto_handle* h, F&& f, int mode = G_PLAIN, hipStream_t st = nullptr) 
     }
 }
 
+// ---- multi-GPU: ranges, gather plans, collectives (dto_comm.h)
+void set_ranges(dto_handle* h, int rank, int world, const int64_t* k_lo, const int64_t* k_hi) {
+    if (world < 1 || rank < 0 || rank >= world) throw HipError{"dto_comm: bad rank / world"};
+    std::vector<std::pair<int64_t, int64_t>> rr;
+    for (int r = 0; r < world; ++r) {
+        if (k_lo[r] < 1 || k_hi[r] < k_lo[r] || k_hi[r] > h->N) throw HipError{"dto_comm: a rank's knot range is out of bounds"};
+        rr.emplace_back(k_lo[r], k_hi[r]);
+    }
+    if (rr[rank].first != h->k_lo || rr[rank].second != h->k_hi)
+        throw HipError{"dto_comm: this rank's entry of the knot ranges is not the handle's own shard"};
+    std::vector<Slab> sl[3];
+    for (int r = 0; r < world; ++r) {
+        const ShardExtents e = shard_extents(h, rr[r].first, rr[r].second);
+        sl[0].push_back(Slab{e.jac_lo, e.jac_len});
+        sl[1].push_back(Slab{e.hess_lo, e.hess_len});
+        sl[2].push_back(Slab{e.grad_lo, e.grad_len});
+    }
+    h->gather_plan[0] = make_gather_plan(sl[0], h->jac_nnz);
+    h->gather_plan[1] = make_gather_plan(sl[1], h->hess_nnz);
+    h->gather_plan[2] = make_gather_plan(sl[2], h->n_vars);
+    h->cons_segments.clear();
+    h->cons_segment_root.clear();
+    for (int r = 0; r < world; ++r)
+        for (auto& sg : shard_row_segments(h, rr[r].first, rr[r].second)) {
+            h->cons_segments.push_back(Slab{sg.first, sg.second});
+            h->cons_segment_root.push_back(r);
+        }
+    h->rank_ranges.swap(rr);
+    h->comm_rank = rank;
+}
+
+const GatherPlan& plan_of(const dto_handle* h, int vector) {
+    if (h->rank_ranges.empty()) throw HipError{"no knot ranges yet: dto_comm_create / dto_comm_set_ranges first"};
+    if (vector < DTO_VECTOR_JACOBIAN || vector > DTO_VECTOR_GRADIENT) throw HipError{"dto_gather: unknown vector kind"};
+    return h->gather_plan[vector - 1];
+}
+
+void gather_vector(dto_handle* h, int vector, double* dbuf, hipStream_t st) {
+    const GatherPlan& pl = plan_of(h, vector);
+    if (!h->comm) throw HipError{"dto_gather: no communicator (dto_comm_create)"};
+    if (vector == DTO_VECTOR_HESSIAN && !h->eval_hessian) throw HipError{"handle was created with eval_hessian = 0"};
+    std::string e;
+    if (pl.in_place) {
+        e = h->comm->all_gather_in_place(dbuf, pl.n, st);
+    } else {
+        std::vector<int> root(pl.slabs.size());
+        for (size_t r = 0; r < root.size(); ++r) root[r] = (int)r;
+        e = h->comm->broadcast_slabs(dbuf, pl.slabs, root, st);
+    }
+    if (!e.empty()) throw HipError{e};
+}
+
+// the comm entry points touch no sweep state: errors come back at once, nothing is deferred
+template <class F>
+int comm_guarded(dto_handle* h, F&& f, bool needs_device = true) {
+    if (!h) return fail(nullptr, "null handle");
+    try {
+        if (needs_device) {
+            if (h->structure_only) throw HipError{"structure-only handle (created with device < 0): no collectives without a GPU"};
+            HIP_CHECK(hipSetDevice(h->device));
+        }
+        f();
+        return 0;
+    } catch (const HipError& e) {
+        return fail(h, e.msg);
+    } catch (const std::exception& e) {
+        return fail(h, e.what());
+    }
+}
+
 void upload_Z(dto_handle* h, const double* Z) {
     HIP_CHECK(hipMemcpyAsync(h->d_Z, Z, sizeof(double) * (size_t)h->n_vars, hipMemcpyHostToDevice, h->stream));
 }
@@ -1679,19 +1802,16 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             h->d_colptr = own(h, dupload(h->colptr));
             P.colptr = h->d_colptr;
         }
-        const int64_t c_lo = P.kn_lo * h->z, c_hi = (P.kn_lo + P.n_knots) * h->z;
-        P.jac_lo = h->colptr[c_lo];
-        P.hess_lo = hess_block_start(h, P.kn_lo);
-        P.grad_lo = c_lo;
+        const ShardExtents ext = shard_extents(h, h->k_lo, h->k_hi);
+        P.jac_lo = ext.jac_lo;
+        P.hess_lo = ext.hess_lo;
+        P.grad_lo = ext.grad_lo;
         dto_shard_info& I = h->info;
         I.k_lo = h->k_lo; I.k_hi = h->k_hi;
         I.n_vars = h->n_vars; I.n_cons = h->n_cons; I.jac_nnz = h->jac_nnz; I.hess_nnz = h->hess_nnz;
-        I.grad_lo = c_lo;
-        I.grad_len = c_hi - c_lo + (h->k_hi == h->N ? h->gd : 0);
-        I.jac_lo = P.jac_lo;
-        I.jac_len = h->colptr[h->k_hi == h->N ? h->n_vars : c_hi] - P.jac_lo;  // global columns ride with the last knot
-        I.hess_lo = P.hess_lo;
-        I.hess_len = hess_block_start(h, P.kn_lo + P.n_knots) - P.hess_lo + (h->k_hi == h->N ? (int64_t)h->tail_rows.size() : 0);
+        I.grad_lo = ext.grad_lo; I.grad_len = ext.grad_len;
+        I.jac_lo = ext.jac_lo; I.jac_len = ext.jac_len;      // global columns ride with the last knot
+        I.hess_lo = ext.hess_lo; I.hess_len = ext.hess_len;
         P.tail_lo = h->k_hi == h->N ? h->hess_block_nnz - P.hess_lo : -1;
         if (!sonly) {
             P.tail_colptr = own(h, dupload(h->tail_colptr));
@@ -1706,7 +1826,6 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) h->der[h->integ_index[i]].lrow_off = lrow;
             else if (h->integ_kind[i] == DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR) h->tdb[h->integ_index[i]].place.lrow_off = lrow;
             else h->ext_int[h->integ_index[i]].lrow_off = lrow;
-            if (P.n_int > 0) h->row_segments.emplace_back(h->integ_row_off[i] + P.kn_lo * dd, P.n_int * dd);
             lrow += P.n_int * dd;
         }
         for (auto& c : h->con) {
@@ -1715,11 +1834,6 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             for (int64_t i = 0; i < c.n_times_total; ++i) {
                 const int64_t kn = c.times0[i];
                 if (kn >= h->N ? h->k_hi != h->N : (kn < P.kn_lo || kn >= P.kn_lo + P.n_knots)) continue;  // pseudo-knot N: last rank
-                if (!h->row_segments.empty() && !times.empty() && tidx.back() == i - 1 &&
-                    h->row_segments.back().first + h->row_segments.back().second == c.row_off + i * c.g_dim)
-                    h->row_segments.back().second += c.g_dim;
-                else
-                    h->row_segments.emplace_back(c.row_off + i * c.g_dim, c.g_dim);
                 times.push_back(kn);
                 lrows.push_back(lrow);
                 lrow += c.g_dim;
@@ -1764,6 +1878,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 }
             }
         }
+        h->row_segments = shard_row_segments(h, h->k_lo, h->k_hi);  // the local buffer is their concatenation, in this order
         h->cons_len = lrow;
         I.cons_len = lrow;
         I.n_row_segments = (int32_t)h->row_segments.size();
@@ -2287,6 +2402,115 @@ int dto_eval_jacobian_product(dto_handle* h, const double* Z, const double* w, d
 // y = J(Z)' w -- MOI.eval_constraint_jacobian_transpose_product (evaluator.jl:432-456)
 int dto_eval_jacobian_transpose_product(dto_handle* h, const double* Z, const double* w, double* y) {
     return guarded(h, [&] { jac_product(h, Z, w, y, 1); }, G_BLOCKING);
+}
+
+// ---- multi-GPU: ranges, gather plans, collectives (dto_comm.h)
+int dto_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, "dto_comm_unique_id: null argument");
+    const std::string e = Comm::unique_id(id128);
+    return e.empty() ? 0 : fail(nullptr, e);
+}
+
+int dto_comm_create(dto_handle* h, const void* id128, int32_t rank, int32_t world) {
+    return comm_guarded(h, [&] {
+        if (!id128) throw HipError{"dto_comm_create: null id"};
+        if (h->comm) throw HipError{"dto_comm_create: the handle already has a communicator (dto_comm_destroy first)"};
+        std::string err;
+        std::unique_ptr<Comm> c = Comm::create(id128, rank, world, err);
+        if (!c) throw HipError{err};
+        // every rank's knot range: one 16-byte all-gather
+        if (!h->d_ranges) h->d_ranges = own(h, dalloc<int64_t>(2 * 1024));
+        if (world > 1023) throw HipError{"dto_comm_create: at most 1023 ranks"};
+        const int64_t mine[2] = {h->k_lo, h->k_hi};
+        HIP_CHECK(hipMemcpyAsync(h->d_ranges, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+        err = c->all_gather_i64(h->d_ranges, h->d_ranges + 2, 2, h->stream);
+        if (!err.empty()) throw HipError{err};
+        std::vector<int64_t> all((size_t)2 * world);
+        HIP_CHECK(hipMemcpyAsync(all.data(), h->d_ranges + 2, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        std::vector<int64_t> lo(world), hi(world);
+        for (int r = 0; r < world; ++r) { lo[r] = all[2 * r]; hi[r] = all[2 * r + 1]; }
+        set_ranges(h, rank, world, lo.data(), hi.data());
+        h->comm = std::move(c);
+    });
+}
+
+int dto_comm_set_ranges(dto_handle* h, int32_t rank, int32_t world, const int64_t* k_lo, const int64_t* k_hi) {
+    return comm_guarded(h, [&] {
+        if (!k_lo || !k_hi) throw HipError{"dto_comm_set_ranges: null argument"};
+        if (h->comm) throw HipError{"dto_comm_set_ranges: the handle's communicator already fixed the ranges"};
+        set_ranges(h, rank, world, k_lo, k_hi);
+    }, /*needs_device=*/false);
+}
+
+int dto_comm_destroy(dto_handle* h) {
+    return comm_guarded(h, [&] {
+        h->comm.reset();
+        h->rank_ranges.clear();
+        h->comm_rank = -1;
+    }, /*needs_device=*/!(h && h->structure_only));
+}
+
+int dto_get_gather_layout(const dto_handle* h, int32_t vector, dto_gather_layout* out) {
+    dto_handle* hm = const_cast<dto_handle*>(h);
+    return comm_guarded(hm, [&] {
+        if (!out) throw HipError{"dto_get_gather_layout: null argument"};
+        dto_gather_layout L{};
+        L.world = (int32_t)h->rank_ranges.size();
+        if (vector == DTO_VECTOR_CONSTRAINT) {
+            if (h->rank_ranges.empty()) throw HipError{"no knot ranges yet: dto_comm_create / dto_comm_set_ranges first"};
+            L.total = L.padded_len = h->n_cons;
+            L.own_len = h->cons_len;
+        } else {
+            const GatherPlan& pl = plan_of(h, vector);
+            L.total = pl.total;
+            L.padded_len = pl.padded_len();
+            L.front_pad = pl.in_place ? pl.front : 0;
+            L.own_lo = pl.slabs[h->comm_rank].lo;
+            L.own_len = pl.slabs[h->comm_rank].len;
+            L.in_place_all_gather = pl.in_place ? 1 : 0;
+        }
+        *out = L;
+    }, /*needs_device=*/false);
+}
+
+int dto_gather_slabs(const dto_handle* h, int32_t vector, int64_t* lo, int64_t* len) {
+    dto_handle* hm = const_cast<dto_handle*>(h);
+    return comm_guarded(hm, [&] {
+        if (!lo || !len) throw HipError{"dto_gather_slabs: null argument"};
+        const GatherPlan& pl = plan_of(h, vector);
+        for (size_t r = 0; r < pl.slabs.size(); ++r) { lo[r] = pl.slabs[r].lo; len[r] = pl.slabs[r].len; }
+    }, /*needs_device=*/false);
+}
+
+int dto_gather_jacobian_dev(dto_handle* h, double* dbuf, void* stream) {
+    return comm_guarded(h, [&] { gather_vector(h, DTO_VECTOR_JACOBIAN, dbuf, (hipStream_t)stream); });
+}
+int dto_gather_hessian_dev(dto_handle* h, double* dbuf, void* stream) {
+    return comm_guarded(h, [&] { gather_vector(h, DTO_VECTOR_HESSIAN, dbuf, (hipStream_t)stream); });
+}
+int dto_gather_gradient_dev(dto_handle* h, double* dbuf, void* stream) {
+    return comm_guarded(h, [&] { gather_vector(h, DTO_VECTOR_GRADIENT, dbuf, (hipStream_t)stream); });
+}
+int dto_gather_constraint_dev(dto_handle* h, const double* dg_local, double* dg_full, void* stream) {
+    return comm_guarded(h, [&] {
+        if (!h->comm) throw HipError{"dto_gather: no communicator (dto_comm_create)"};
+        hipStream_t st = (hipStream_t)stream;
+        int64_t at = 0;
+        for (auto& sg : h->row_segments) {  // the local buffer is the concatenation of the rank's segments
+            HIP_CHECK(hipMemcpyAsync(dg_full + sg.first, dg_local + at, sizeof(double) * (size_t)sg.second, hipMemcpyDeviceToDevice, st));
+            at += sg.second;
+        }
+        const std::string e = h->comm->broadcast_slabs(dg_full, h->cons_segments, h->cons_segment_root, st);
+        if (!e.empty()) throw HipError{e};
+    });
+}
+int dto_allreduce_objective_dev(dto_handle* h, double* df, void* stream) {
+    return comm_guarded(h, [&] {
+        if (!h->comm) throw HipError{"dto_allreduce_objective_dev: no communicator (dto_comm_create)"};
+        const std::string e = h->comm->all_reduce_sum(df, 1, (hipStream_t)stream);
+        if (!e.empty()) throw HipError{e};
+    });
 }
 
 // ---- measurement

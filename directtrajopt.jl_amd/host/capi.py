@@ -8,7 +8,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 5
+DTO_ABI_VERSION = 6
 FLAG_GENERAL_PATH_ONLY = 1
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL, INTEGRATOR_TIME_DEPENDENT_BILINEAR = 1, 2, 3, 4
 OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK, OBJECTIVE_EXTERNAL_GLOBAL = 1, 2, 3, 4, 5, 6, 7
@@ -56,6 +56,14 @@ class ShardInfo(C.Structure):
                 ("cons_len", C.c_int64), ("n_row_segments", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GatherLayout(C.Structure):
+    _fields_ = [("total", C.c_int64), ("padded_len", C.c_int64), ("front_pad", C.c_int64), ("own_lo", C.c_int64),
+                ("own_len", C.c_int64), ("in_place_all_gather", C.c_int32), ("world", C.c_int32)]
+
+
+COMM_ID_BYTES = 128
+VECTOR_JACOBIAN, VECTOR_HESSIAN, VECTOR_GRADIENT, VECTOR_CONSTRAINT = 1, 2, 3, 4
+
 H = C.c_void_p
 
 # every symbol include/dto_engine.h declares: name -> (restype, argtypes)
@@ -88,6 +96,17 @@ SYMBOLS = {
     "dto_eval_constraint_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dto_eval_jacobian_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dto_eval_hessian_dev": (C.c_int, [H, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dto_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dto_comm_create": (C.c_int, [H, C.c_void_p, C.c_int32, C.c_int32]),
+    "dto_comm_set_ranges": (C.c_int, [H, C.c_int32, C.c_int32, c_int64_p, c_int64_p]),
+    "dto_comm_destroy": (C.c_int, [H]),
+    "dto_get_gather_layout": (C.c_int, [H, C.c_int32, C.POINTER(GatherLayout)]),
+    "dto_gather_slabs": (C.c_int, [H, C.c_int32, c_int64_p, c_int64_p]),
+    "dto_gather_jacobian_dev": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+    "dto_gather_hessian_dev": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+    "dto_gather_gradient_dev": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+    "dto_gather_constraint_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dto_allreduce_objective_dev": (C.c_int, [H, C.c_void_p, C.c_void_p]),
     "dto_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "dto_profile_enable": (C.c_int, [H, C.c_int32]),
     "dto_profile_reset": (C.c_int, [H]),

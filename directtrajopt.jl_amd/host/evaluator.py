@@ -382,6 +382,56 @@ class Evaluator:
         self._stage_external(Z_host, con_need=2, obj_need=2 if sigma != 0.0 else -1, mu=mu_host)
         self._check(self._lib.dto_eval_hessian_dev(self._h, dZ, float(sigma), dmu, dvals, stream))
 
+    # ---- multi-GPU: the engine's own collectives (RCCL over xGMI behind the C ABI; include/dto_engine.h, "Multi-GPU")
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId: call on ONE rank and hand them to the others (e.g. torch.distributed's
+        broadcast_object_list, MPI, a file)."""
+        lib = load_library()
+        buf = C.create_string_buffer(capi.COMM_ID_BYTES)
+        if lib.dto_comm_unique_id(buf) != 0:
+            raise EngineError(lib.dto_last_error(None).decode())
+        return buf.raw
+
+    def comm_create(self, unique_id, rank, world):
+        """Collective over the ranks: ncclCommInitRank on this handle's device + exchange of the ranks' knot ranges."""
+        buf = C.create_string_buffer(bytes(unique_id), capi.COMM_ID_BYTES)
+        self._check(self._lib.dto_comm_create(self._h, buf, rank, world))
+
+    def comm_set_ranges(self, rank, ranges):
+        """The layout bookkeeping without a communicator (works on structure-only handles): ranges = [(k_lo, k_hi)] per rank."""
+        lo = np.ascontiguousarray([a for a, _ in ranges], dtype=np.int64)
+        hi = np.ascontiguousarray([b for _, b in ranges], dtype=np.int64)
+        self._check(self._lib.dto_comm_set_ranges(self._h, rank, len(ranges), _ip(lo), _ip(hi)))
+
+    def comm_destroy(self):
+        self._check(self._lib.dto_comm_destroy(self._h))
+
+    def gather_layout(self, vector):
+        """dto_get_gather_layout: how to allocate one value vector (capi.VECTOR_*) so that the gather moves every slab in place."""
+        L = capi.GatherLayout()
+        self._check(self._lib.dto_get_gather_layout(self._h, vector, C.byref(L)))
+        return L
+
+    def gather_slabs(self, vector):
+        """[(lo, len)] of every rank's slab of one value vector."""
+        w = self.gather_layout(vector).world
+        lo, ln = np.empty(w, dtype=np.int64), np.empty(w, dtype=np.int64)
+        self._check(self._lib.dto_gather_slabs(self._h, vector, _ip(lo), _ip(ln)))
+        return list(zip(lo.tolist(), ln.tolist()))
+
+    def gather_dev(self, vector, dbuf, stream=0):
+        """All ranks: fill in the other ranks' slabs of the vector allocated per gather_layout (dbuf = the allocation)."""
+        fn = {capi.VECTOR_JACOBIAN: self._lib.dto_gather_jacobian_dev, capi.VECTOR_HESSIAN: self._lib.dto_gather_hessian_dev,
+              capi.VECTOR_GRADIENT: self._lib.dto_gather_gradient_dev}[vector]
+        self._check(fn(self._h, dbuf, stream))
+
+    def gather_constraint_dev(self, dg_local, dg_full, stream=0):
+        self._check(self._lib.dto_gather_constraint_dev(self._h, dg_local, dg_full, stream))
+
+    def allreduce_objective_dev(self, df, stream=0):
+        self._check(self._lib.dto_allreduce_objective_dev(self._h, df, stream))
+
     def set_option(self, name, value):
         """dto_set_option: ``reuse_forward_sweep`` (solver loops evaluate g, J, H at the same point), ``expm_form``
         (0 = by cost, 2 / 3 = two- / three-product form of the Jacobian's matrix exponential)."""

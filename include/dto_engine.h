@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 5
+#define DTO_ABI_VERSION 6
 
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
@@ -254,6 +254,58 @@ int dto_eval_constraint_dev(dto_handle* h, const double* dZ, double* dg, void* s
 int dto_eval_jacobian_dev(dto_handle* h, const double* dZ, double* dvals, void* stream);
 int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const double* dmu,
                          double* dvals, void* stream);
+
+/* ---- Multi-GPU: knot ranges sharded over the GPUs of one node, one process (or thread with its own device) per GPU
+ * (BASELINE configs[3] "knot range sharded across 8 x MI355X (RCCL allgather)").  The engine owns the RCCL
+ * communicator (SURVEY.md §8b "Ownership").  No callback needs a collective: every rank's Jacobian / Hessian / gradient
+ * output is one contiguous slab of the global value vector.  The entry points below serve a consumer that wants the WHOLE
+ * vector on every GPU (MadNLP's KKT assembly in GPU mode, ext/MadNLPSolverExt/solver.jl:81,
+ * src/solvers/madnlp_solver/options.jl:12-16) and the objective's sum over the ranks.
+ *
+ *   1. one rank:   dto_comm_unique_id(id)                  -- hand the 128 bytes to the others (MPI, a file, a socket)
+ *   2. every rank: dto_comm_create(h, id, rank, world)     -- collective; exchanges the ranks' knot ranges
+ *   3. every rank: dto_get_gather_layout(h, DTO_VECTOR_JACOBIAN, &L); allocate L.padded_len doubles of device memory `buf`;
+ *                  the global value vector is buf + L.front_pad, this rank's slab starts at buf + L.front_pad + L.own_lo
+ *   4. per call:   dto_eval_jacobian_dev(h, dZ, buf + L.front_pad + L.own_lo, stream);
+ *                  dto_gather_jacobian_dev(h, buf, stream);   -- all ranks, same order; enqueued on `stream`
+ *
+ * With contiguous knot ranges in rank order the gather is ONE in-place ncclAllGather on `buf` (L.in_place_all_gather = 1:
+ * the first and the last rank's slabs are a boundary half-block shorter than the others, which is what front_pad and the
+ * padding behind the vector absorb -- a few hundred KB on 17.6 GB); any other assignment of knots to handles (a rank's knots
+ * over two handles to overlap the gather of one with the compute of the other) is served by one in-place ncclBroadcast per
+ * rank inside a group call, and padded_len = total.  Padding is never read as data.
+ * dto_comm_set_ranges is the same bookkeeping WITHOUT a communicator (also on structure-only handles): for callers that move
+ * the slabs with a transport of their own and only want the layout. */
+#define DTO_COMM_ID_BYTES 128
+#define DTO_VECTOR_JACOBIAN 1
+#define DTO_VECTOR_HESSIAN 2
+#define DTO_VECTOR_GRADIENT 3
+#define DTO_VECTOR_CONSTRAINT 4 /* g: a rank's rows are several segments of the global vector (dto_shard_rows), moved by
+                                   one broadcast per segment; layout: total = n_cons, no padding, own_lo / own_len unused */
+typedef struct dto_gather_layout {
+    int64_t total;       /* length of the global vector */
+    int64_t padded_len;  /* doubles to allocate */
+    int64_t front_pad;   /* the global vector starts here inside the allocation */
+    int64_t own_lo;      /* this rank's slab inside the global vector (= dto_shard_info.*_lo) */
+    int64_t own_len;
+    int32_t in_place_all_gather; /* 1: one ncclAllGather moves every slab; 0: one broadcast per rank */
+    int32_t world;
+} dto_gather_layout;
+int dto_comm_unique_id(void* id128);
+int dto_comm_create(dto_handle* h, const void* id128, int32_t rank, int32_t world);
+int dto_comm_set_ranges(dto_handle* h, int32_t rank, int32_t world, const int64_t* k_lo, const int64_t* k_hi);
+int dto_comm_destroy(dto_handle* h);
+int dto_get_gather_layout(const dto_handle* h, int32_t vector, dto_gather_layout* out);
+/* every rank's (lo, len) of one value vector, [world] each (VECTOR_JACOBIAN / HESSIAN / GRADIENT) */
+int dto_gather_slabs(const dto_handle* h, int32_t vector, int64_t* lo, int64_t* len);
+int dto_gather_jacobian_dev(dto_handle* h, double* dbuf, void* stream);
+int dto_gather_hessian_dev(dto_handle* h, double* dbuf, void* stream);
+int dto_gather_gradient_dev(dto_handle* h, double* dbuf, void* stream);
+/* dg_full [n_cons]: the rank's local rows (dg_local, as dto_eval_constraint_dev wrote them) are copied to their global
+ * positions, the other ranks' segments arrive by broadcast */
+int dto_gather_constraint_dev(dto_handle* h, const double* dg_local, double* dg_full, void* stream);
+/* *df := sum over the ranks of *df (the objective's per-shard partial sums, evaluator.jl:304); ncclAllReduce on `stream` */
+int dto_allreduce_objective_dev(dto_handle* h, double* df, void* stream);
 
 /* Options (name, value); unknown names are an error.
  *   "reuse_forward_sweep" (default 0): interior-point solvers evaluate g, J and H at the same point one after the

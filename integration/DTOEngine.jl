@@ -32,7 +32,7 @@ using ..Constraints: AbstractNonlinearConstraint, NonlinearKnotPointConstraint
 using ..CommonInterface: evaluate!, eval_jacobian, eval_hessian_of_lagrangian
 
 const lib = get(ENV, "DTO_ENGINE_LIB", "libdto_engine.so")
-const DTO_ABI_VERSION = Int32(5)
+const DTO_ABI_VERSION = Int32(6)
 
 const DTO_INTEGRATOR_BILINEAR = Int32(1)
 const DTO_INTEGRATOR_DERIVATIVE = Int32(2)

@@ -38,7 +38,27 @@ def test_single_gpu_line():
     assert d["config"]["outputs_finite"] is True
 
 
-def test_two_ranks_on_one_device_print_the_gather_block():
+def test_gpus_2_without_torchrun_starts_two_ranks_itself():
+    """`bench.py --gpus 2` started plainly (WORLD_SIZE unset) launches its two ranks as a child torchrun before touching the
+    GPU and relays ONE line with n_gpus = 2; the gather block goes through the engine's C-ABI collectives (two real RCCL ranks:
+    on one device they pose as two hosts and use the socket transport), the strong-scaling block splits the same knots."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--n", "64", "--knots", "600", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["knots_total"] == 1200 and d["scaling"] == "weak"
+    g = d["gather"]
+    assert "error" not in g and "overlapped_error" not in g, g
+    assert g["n_ranks"] == 2 and g["sampled_finite"] is True and "ncclAllGather" in g["collective"] and "C ABI" in g["transport"]
+    assert g["ms_per_step_overlapped"] > 0 and g["overlapped_vs_sequential_max_rel_diff_sampled"] <= 1e-10
+    st = d["strong_scaling"]
+    assert st["scaling"] == "strong" and st["knots_total"] == 600 and st["knots_per_gpu"] == 300 and st["value"] > 0 and st["outputs_finite"]
+
+
+def test_strong_scaling_line_under_torchrun():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -46,12 +66,16 @@ def test_two_ranks_on_one_device_print_the_gather_block():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
-                        "--states", "64", "--knots", "600", "--steps", "2", "--warmup", "1"],
+                        "--states", "64", "--knots", "600", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--no-gather"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["knots_total"] == 1200 and d["scaling"] == "weak"
-    g = d["gather"]
-    assert "error" not in g and "overlapped_error" not in g, g
-    assert g["n_ranks"] == 2 and g["sampled_finite"] is True
-    assert g["ms_per_step_overlapped"] > 0 and g["overlapped_vs_sequential_max_rel_diff_sampled"] <= 1e-10
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["knots_total"] == 600 and d["config"]["knots_per_gpu"] == 300
+    assert abs(d["value"] - 600 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_asking_for_more_gpus_than_visible_fails_loudly():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "7", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
