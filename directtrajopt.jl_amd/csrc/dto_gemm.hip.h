@@ -26,6 +26,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <int TM_, int TN_, int WR_ = 2, int WC_ = 2, int KB_ = 16>
 struct GemmShape {
     static constexpr int TM = TM_, TN = TN_, WR = WR_, WC = WC_, KB = KB_;
+    static constexpr bool PAIRED = false;
     static constexpr int THREADS = WR * WC * 64;
     static constexpr int LDA_S = TM + 16;  // (TM+16) mod 32 == 16 for TM multiple of 32
     static constexpr int LDB_S = KB + 2;
@@ -227,6 +228,130 @@ __device__ __forceinline__ void gemm_accumulate_dma(GemmAccS<C>& acc, const doub
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Paired rows" core (round 3): 16-byte LDS fragment reads and 16-byte epilogue accesses.
+//
+// Accumulator tile ti of a wave covers the rows 32 (ti/2) + 2 lr + (ti & 1) of the wave tile instead of 16 ti + lr, so the
+// two tiles 2p, 2p+1 of a lane hold two CONSECUTIVE rows: one ds_read_b128 feeds both A fragments, and an epilogue moves 16
+// bytes per lane -- 256 contiguous bytes per 16 lanes of a column-major C (half the vector-memory instructions of the 8-byte
+// form; cdna_hip_programming.md T21).  The B fragments of TWO k-steps come from one ds_read_b128 as well: the 8 k's of a
+// double step run in the order {0,2,4,6}, {1,3,5,7} -- lane group lq supplies k = 2 lq + s in step s, for both operands, and
+// a sum over k does not care.  LDS images (double buffered, one barrier per 16-deep panel):
+//   As[k][TM]      unpadded, pitch TM*8 = a multiple of 256 B: the b128 lane groups {0-3,12-15,20-27}, ... of two adjacent k
+//                  rows cover all 64 banks once; a K row is one wave-contiguous KB piece, so A can come by LDS-DMA
+//                  (`global_load_lds_dwordx4`, no staging registers) exactly as it lies in memory
+//   Bs[n][KB + 4]  pitch 160 B: conflict-free for the b128 reads (16-byte slot = 10 n + lq mod 16 is a bijection on every
+//                  lane group) and for the staging stores (8 consecutive lanes = 8 consecutive slots)
+// Measured (tools/bgemm_probe4, 2000 x 256^3, one box, steady state): 8-byte core 59.4-60.0 TFLOP/s, this core 60.5-61.1
+// with register staging and 62.2-62.5 with A by DMA; rocBLAS (torch.bmm) 52 / 61 (product / squaring) on another box.
+template <int TM_, int TN_, int WR_ = 2, int WC_ = 2>
+struct GemmShapeP {
+    static constexpr int TM = TM_, TN = TN_, WR = WR_, WC = WC_, KB = 16;
+    static constexpr bool PAIRED = true;
+    static constexpr int THREADS = WR * WC * 64;
+    static constexpr int LDB_S = KB + 4;
+    static constexpr int AS_ELEMS = KB * TM;
+    static constexpr int BS_ELEMS = TN * LDB_S;
+    static constexpr int SMEM_DOUBLES = 2 * (AS_ELEMS + BS_ELEMS);
+    static constexpr int WTM = TM / WR, WTN = TN / WC;
+    static constexpr int MT = WTM / 16, NT = WTN / 16;
+    static constexpr int A_LD = (TM * KB / 2) / THREADS, B_LD = (TN * KB / 2) / THREADS;
+    static constexpr int A_PIECES = KB / (THREADS / 64);  // DMA pieces (K rows) per wave and panel
+    static_assert(TM % 32 == 0 && WTM % 32 == 0 && WTN % 16 == 0, "wave tile: pairs of 16-row tiles");
+    static_assert((TM * KB / 2) % THREADS == 0 && (TN * KB / 2) % THREADS == 0 && KB % (THREADS / 64) == 0, "panel loads must divide evenly");
+    static_assert(TM == 128, "a DMA piece is one K row of 128 doubles");
+};
+
+template <class C, bool DMA_A>
+__device__ __forceinline__ void gemm_accumulate_p(GemmAccS<C>& acc, const double* __restrict__ A, int lda,
+                                                  const double* __restrict__ B, int ldb, int Klen, double* smem) {
+    constexpr int TM = C::TM, KB = C::KB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WC, wn = wave % C::WC;
+    const int lr = lane & 15, lq = lane >> 4;
+    double* As = smem;
+    double* Bs = smem + 2 * C::AS_ELEMS;
+    d2 ra[DMA_A ? 1 : C::A_LD], rb[C::B_LD];
+    const int nkb = Klen / KB;
+    auto load_panel = [&](int kb, int buf) {
+        const int k0 = kb * KB;
+        if constexpr (DMA_A) {
+#pragma unroll
+            for (int q = 0; q < C::A_PIECES; ++q) {
+                const int k = wave + (C::THREADS / 64) * q;
+                __builtin_amdgcn_global_load_lds(DTO_GLB_PTR(A + (size_t)(k0 + k) * lda + 2 * lane), DTO_LDS_PTR(As + buf * C::AS_ELEMS + k * TM), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::A_LD; ++i) {
+                const int idx = tid + C::THREADS * i;
+                ra[i] = *reinterpret_cast<const d2*>(A + (size_t)(k0 + idx / (TM / 2)) * lda + 2 * (idx % (TM / 2)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+            const int idx = tid + C::THREADS * i;
+            rb[i] = *reinterpret_cast<const d2*>(B + (size_t)(idx / (KB / 2)) * ldb + k0 + 2 * (idx % (KB / 2)));
+        }
+    };
+    auto store_panel = [&](int buf) {
+        if constexpr (!DMA_A) {
+#pragma unroll
+            for (int i = 0; i < C::A_LD; ++i) {
+                const int idx = tid + C::THREADS * i;
+                *reinterpret_cast<d2*>(As + buf * C::AS_ELEMS + (idx / (TM / 2)) * TM + 2 * (idx % (TM / 2))) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+            const int idx = tid + C::THREADS * i;
+            *reinterpret_cast<d2*>(Bs + buf * C::BS_ELEMS + (idx / (KB / 2)) * C::LDB_S + 2 * (idx % (KB / 2))) = rb[i];
+        }
+    };
+    load_panel(0, 0);
+    store_panel(0);
+    __syncthreads();  // (its fence also waits for the DMA pieces: vmcnt(0) before the barrier)
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) load_panel(kb + 1, buf ^ 1);
+        const double* as = As + buf * C::AS_ELEMS + wm * C::WTM + 2 * lr;
+        const double* bs = Bs + buf * C::BS_ELEMS + (wn * C::WTN + lr) * C::LDB_S + 2 * lq;
+#pragma unroll
+        for (int k8 = 0; k8 < KB; k8 += 8) {
+            d2 b2[C::NT];
+#pragma unroll
+            for (int tj = 0; tj < C::NT; ++tj) b2[tj] = *reinterpret_cast<const d2*>(bs + 16 * tj * C::LDB_S + k8);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                d2 a2[C::MT / 2];
+#pragma unroll
+                for (int p = 0; p < C::MT / 2; ++p) a2[p] = *reinterpret_cast<const d2*>(as + (k8 + 2 * lq + s) * TM + 32 * p);
+#pragma unroll
+                for (int ti = 0; ti < C::MT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < C::NT; ++tj)
+                        acc.v[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(s ? b2[tj].y : b2[tj].x, (ti & 1) ? a2[ti / 2].y : a2[ti / 2].x,
+                                                                             acc.v[ti][tj], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < nkb) store_panel(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// Coordinates of the calling lane's accumulator elements inside the TM x TN tile, paired-rows core: acc.v[2p][tj][r] and
+// acc.v[2p+1][tj][r] are rows row_base + 32 p and row_base + 32 p + 1 of column col_base + 16 tj + 4 r.
+template <class S>
+struct GemmCoordP {
+    int row_base, col_base;
+    __device__ __forceinline__ GemmCoordP() {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        row_base = (wave / S::WC) * S::WTM + 2 * (lane & 15);
+        col_base = (wave % S::WC) * S::WTN + (lane >> 4);
+    }
+};
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // a 16-byte access at an 8-byte-aligned address (slab columns)
 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_accumulate(GemmAcc<TM, TN>& acc, const double* __restrict__ A, int lda,

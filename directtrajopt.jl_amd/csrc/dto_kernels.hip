@@ -141,42 +141,79 @@ void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const Basi
     hipLaunchKernelGGL(k_basis_coef, dim3(nbpad), dim3(128), 0, st, P, B, bs, dZ, int0, nb, taylor);
 }
 
+// Epilogue shared by the generator-subspace GEMMs: store the tile (out may be null: norms only) and accumulate the column
+// abs-sums.  A wave's 64 rows lie inside ONE column of the npad x npad matrix (npad multiple of 64 and of the wave tile), so
+// the 16 lanes that share an interval reduce among themselves and issue one atomic per (interval, matrix column).
+template <class Cfg>
+__device__ __forceinline__ void basis_epilogue(const GemmAccS<Cfg>& acc, int npad, int nb, int rt, int ct, double* __restrict__ out,
+                                               double* __restrict__ colsum) {
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    static_assert(Cfg::WTM == 64, "column sums assume 64-row wave tiles");
+    const int64_t nn = (int64_t)npad * npad;
+    const int wave_row0 = rt * TM + ((threadIdx.x >> 6) / Cfg::WC) * Cfg::WTM;
+    if constexpr (Cfg::PAIRED) {
+        GemmCoordP<Cfg> co;
+        const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
+#pragma unroll
+        for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = col0 + 16 * tj + 4 * r;
+                double asum = 0.0;
+#pragma unroll
+                for (int p = 0; p < Cfg::MT / 2; ++p) {
+                    const d2 v = {acc.v[2 * p][tj][r], acc.v[2 * p + 1][tj][r]};
+                    if (out && col < nb) __builtin_nontemporal_store(v, reinterpret_cast<d2*>(&out[(int64_t)col * nn + row0 + 32 * p]));
+                    asum += fabs(v.x) + fabs(v.y);
+                }
+                if (colsum) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
+                    if ((threadIdx.x & 15) == 0 && col < nb) atomicAdd(&colsum[(int64_t)col * npad + wave_row0 / npad], asum);
+                }
+            }
+    } else {
+        GemmCoordS<Cfg> co;
+        const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
+#pragma unroll
+        for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = col0 + 16 * tj + 4 * r;
+                double asum = 0.0;
+#pragma unroll
+                for (int ti = 0; ti < Cfg::MT; ++ti) {
+                    if (out && col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
+                    asum += fabs(acc.v[ti][tj][r]);
+                }
+                if (colsum) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
+                    if ((threadIdx.x & 15) == 0 && col < nb) atomicAdd(&colsum[(int64_t)col * npad + wave_row0 / npad], asum);
+                }
+            }
+    }
+}
+template <class Cfg>
+__device__ __forceinline__ void basis_accumulate(GemmAccS<Cfg>& acc, const BasisSet& bs, int64_t nn, int rt, int ct, double* smem) {
+    const double* A = bs.S + (int64_t)rt * Cfg::TM;
+    const double* B = bs.coef + (int64_t)ct * Cfg::TN * bs.cntpad;
+    if constexpr (Cfg::PAIRED) gemm_accumulate_p<Cfg, true>(acc, A, (int)nn, B, bs.cntpad, bs.cntpad, smem);
+    else gemm_accumulate_s<Cfg>(acc, A, (int)nn, B, bs.cntpad, bs.cntpad, nullptr, smem);
+}
+
 // out[:, b] = S * coef[:, b]  for the nb intervals of the chunk (FP64 MFMA, same GEMM core).
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::THREADS, 2) k_basis_gemm(int npad, int nb, BasisSet bs, double* __restrict__ out,
                                                                 double* __restrict__ colsum) {
-    constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
+    __shared__ __attribute__((aligned(1024))) double smem[Cfg::SMEM_DOUBLES];
     const int64_t nn = (int64_t)npad * npad;
-    const int row_tiles = (int)(nn / TM);
+    const int row_tiles = (int)(nn / Cfg::TM);
     const int rt = blockIdx.x % row_tiles, ct = blockIdx.x / row_tiles;
     GemmAccS<Cfg> acc;
     acc.zero();
-    gemm_accumulate_s<Cfg>(acc, bs.S + (int64_t)rt * TM, (int)nn, bs.coef + (int64_t)ct * TN * bs.cntpad, bs.cntpad,
-                           bs.cntpad, nullptr, smem);
-    GemmCoordS<Cfg> co;
-    const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
-#pragma unroll
-    for (int tj = 0; tj < Cfg::NT; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = col0 + 16 * tj + 4 * r;
-            double asum = 0.0;
-#pragma unroll
-            for (int ti = 0; ti < Cfg::MT; ++ti) {
-                if (out && col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
-                asum += fabs(acc.v[ti][tj][r]);
-            }
-            if (colsum) {
-                // the wave's 64 rows lie inside ONE column of the npad x npad matrix (npad multiple of 128):
-                // reduce over the 16 lanes sharing this interval, then one atomic per (interval, matrix column)
-                static_assert(Cfg::WTM == 64, "column sums assume 64-row wave tiles");
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
-                if ((threadIdx.x & 15) == 0 && col < nb)
-                    atomicAdd(&colsum[(int64_t)col * npad + (rt * TM + (co.row_base & ~63)) / npad], asum);
-            }
-        }
+    basis_accumulate<Cfg>(acc, bs, nn, rt, ct, smem);
+    basis_epilogue<Cfg>(acc, npad, nb, rt, ct, out, colsum);
 }
 __global__ void k_norm_from_colsum(int npad, int nb, const double* __restrict__ colsum, double* __restrict__ norms, int which,
                                    unsigned long long* d2max) {
@@ -208,8 +245,7 @@ struct BasisMulti {
 // write-bound sets with the MFMA-bound ones.
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::THREADS, 2) k_basis_gemm_multi(int npad, int nb, BasisMulti M) {
-    constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    __shared__ __attribute__((aligned(16))) double smem[Cfg::SMEM_DOUBLES];
+    __shared__ __attribute__((aligned(1024))) double smem[Cfg::SMEM_DOUBLES];
     const int which = blockIdx.x % M.nsets, tile = blockIdx.x / M.nsets;
     BasisSet bs = M.bs[0];
     double* out = M.out[0];
@@ -218,40 +254,28 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) k_basis_gemm_multi(int npad, 
     for (int q = 1; q < 3; ++q)
         if (q == which) { bs = M.bs[q]; out = M.out[q]; colsum = M.colsum[q]; }
     const int64_t nn = (int64_t)npad * npad;
-    const int row_tiles = (int)(nn / TM);
+    const int row_tiles = (int)(nn / Cfg::TM);
     const int rt = tile % row_tiles, ct = tile / row_tiles;
     GemmAccS<Cfg> acc;
     acc.zero();
-    gemm_accumulate_s<Cfg>(acc, bs.S + (int64_t)rt * TM, (int)nn, bs.coef + (int64_t)ct * TN * bs.cntpad, bs.cntpad,
-                           bs.cntpad, nullptr, smem);
-    GemmCoordS<Cfg> co;
-    const int row0 = rt * TM + co.row_base, col0 = ct * TN + co.col_base;
-#pragma unroll
-    for (int tj = 0; tj < Cfg::NT; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = col0 + 16 * tj + 4 * r;
-            double asum = 0.0;
-#pragma unroll
-            for (int ti = 0; ti < Cfg::MT; ++ti) {
-                if (col < nb) __builtin_nontemporal_store(acc.v[ti][tj][r], &out[(int64_t)col * nn + row0 + 16 * ti]);
-                asum += fabs(acc.v[ti][tj][r]);
-            }
-            static_assert(Cfg::WTM == 64, "column sums assume 64-row wave tiles");
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
-            if ((threadIdx.x & 15) == 0 && col < nb)
-                atomicAdd(&colsum[(int64_t)col * npad + (rt * TM + (co.row_base & ~63)) / npad], asum);
-        }
+    basis_accumulate<Cfg>(acc, bs, nn, rt, ct, smem);
+    basis_epilogue<Cfg>(acc, npad, nb, rt, ct, out, colsum);
 }
 void launch_basis_gemm_multi(hipStream_t st, int npad, int nb, int nbpad, int nsets, const BasisSet* bs, double* const* out,
                              double* const* colsum) {
     const int64_t nn = (int64_t)npad * npad;
-    using C = GemmShape<128, 128, 2, 4, 16>;
     BasisMulti M{};
     M.nsets = nsets;
     for (int q = 0; q < nsets; ++q) { M.bs[q] = bs[q]; M.out[q] = out[q]; M.colsum[q] = colsum[q]; }
-    hipLaunchKernelGGL((k_basis_gemm_multi<C>), dim3((unsigned)((nn / 128) * (nbpad / 128) * nsets)), dim3(C::THREADS), 0, st, npad, nb, M);
+    const dim3 grid((unsigned)((nn / 128) * (nbpad / 128) * nsets));
+    static const int core = tune_int("DTO_BASIS_CORE", 1);  // 1: paired-rows core (round 3), 0: the 8-byte core
+    if (core == 1) {
+        using C = GemmShapeP<128, 128, 2, 4>;
+        hipLaunchKernelGGL((k_basis_gemm_multi<C>), grid, dim3(C::THREADS), 0, st, npad, nb, M);
+    } else {
+        using C = GemmShape<128, 128, 2, 4, 16>;
+        hipLaunchKernelGGL((k_basis_gemm_multi<C>), grid, dim3(C::THREADS), 0, st, npad, nb, M);
+    }
 }
 __global__ void k_basis_coef_multi(KProb P, KBil B, BasisMulti M, const double* __restrict__ Z, int64_t int0, int nb) {
     const int b = blockIdx.x;
@@ -312,8 +336,15 @@ void launch_basis_gemm(hipStream_t st, int npad, int nb, int nbpad, const BasisS
     const int64_t nn = (int64_t)npad * npad;
     // 8 waves of 64x32 per 128x128 tile: the K loop is only 1..8 panels long, more waves hide its prologue and the
     // store-heavy epilogue better than 4 waves of 64x64 (measured -7 % per launch at 256x2000; 128x64 tiles +9 %)
-    using C = GemmShape<128, 128, 2, 4, 16>;
-    hipLaunchKernelGGL((k_basis_gemm<C>), dim3((unsigned)((nn / 128) * (nbpad / 128))), dim3(C::THREADS), 0, st, npad, nb, bs, out, colsum);
+    const dim3 grid((unsigned)((nn / 128) * (nbpad / 128)));
+    static const int core = tune_int("DTO_BASIS_CORE", 1);
+    if (core == 1) {
+        using C = GemmShapeP<128, 128, 2, 4>;
+        hipLaunchKernelGGL((k_basis_gemm<C>), grid, dim3(C::THREADS), 0, st, npad, nb, bs, out, colsum);
+    } else {
+        using C = GemmShape<128, 128, 2, 4, 16>;
+        hipLaunchKernelGGL((k_basis_gemm<C>), grid, dim3(C::THREADS), 0, st, npad, nb, bs, out, colsum);
+    }
 }
 
 // One wavefront per column c of the owned knots: walk the column's entries in the structure's order
@@ -618,6 +649,103 @@ k_bgemm(BGemmArgs a) {
     }
 }
 
+// The same batched product on the paired-rows core (dto_gemm.hip.h, round 3): 16-byte fragment reads, A panels by LDS-DMA
+// (DMA_A) or through registers, every epilogue access 16 bytes per lane.  Epilogue semantics are those of k_bgemm.
+template <class Cfg, int EPI, bool DMA_A>
+__global__ void __launch_bounds__(Cfg::THREADS, (Cfg::THREADS / 256) * 2)
+k_bgemm_p(BGemmArgs a) {
+    __shared__ __attribute__((aligned(1024))) double smem[Cfg::SMEM_DOUBLES];
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, MP = Cfg::MT / 2;
+    const int tiles_r = a.npad / TM;
+    const int tpm = tiles_r * (a.npad / TN);
+    const int total = batch_tile_count(a.nbatch, tpm);
+    const int64_t nn = (int64_t)a.npad * a.npad;
+    GemmCoordP<Cfg> co;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        int b, tile;
+        if (!decode_batch_tile(v, a.nbatch, tpm, b, tile)) continue;
+        int s_b = 0;
+        if (EPI == EPI_SQUARE) {
+            s_b = a.s[b];
+            if (a.it >= s_b) continue;  // this interval needs no further squaring
+        }
+        const int tr = tile % tiles_r, tc = tile / tiles_r;
+        const double* Ab = a.A + b * nn + (int64_t)tr * TM;
+        const double* Bb = a.B + b * nn + (int64_t)tc * TN * a.npad;
+
+        GemmAccS<Cfg> acc;
+        acc.zero();
+        gemm_accumulate_p<Cfg, DMA_A>(acc, Ab, a.npad, Bb, a.npad, a.npad, smem);
+
+        const int row0 = tr * TM + co.row_base, col0 = tc * TN + co.col_base;
+        // -result into the Jacobian slab (x_k columns of the interval's own rows, evaluator.jl:514-525 /
+        // bilinear_integrator.jl:111-131): the last squaring, or the last polynomial product of an interval that needs none
+        const bool to_slab = (EPI == EPI_SQUARE && a.it == s_b - 1) || (EPI == EPI_HORNER && a.vals != nullptr && a.s[b] == 0);
+        double* Cb = a.C + b * nn;
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr, *M5 = nullptr;
+        double* Cb2 = nullptr;
+        if (epi_poly(EPI)) {
+            const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
+            c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
+            M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn; M4 = a.M4 + b * nn;
+            if (epi_dual(EPI)) {
+                const double* ef = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base2;
+                e0 = ef[0]; e1 = ef[1]; e2 = ef[2]; e3 = ef[3]; e4 = ef[4];
+                Cb2 = a.C2 + b * nn;
+                if (EPI == EPI_DUAL5) { M5 = a.M5 + b * nn; c5 = cf[5]; e5 = ef[5]; }
+            }
+        }
+#pragma unroll
+        for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = col0 + 16 * tj + 4 * r;
+                int64_t slab_base = 0;
+                if ((EPI == EPI_SQUARE || EPI == EPI_HORNER) && to_slab && col < a.Bi.n)
+                    slab_base = jac_pos(a.P, a.P.colptr, a.int0 + b, a.Bi.x_off + col, a.Bi.pre, a.Bi.n, 1, 0);
+#pragma unroll
+                for (int p = 0; p < MP; ++p) {
+                    const int row = row0 + 32 * p;  // even; the lane also holds row + 1
+                    const int64_t off = (int64_t)col * a.npad + row;
+                    d2 v2 = {acc.v[2 * p][tj][r], acc.v[2 * p + 1][tj][r]};
+                    if (epi_poly(EPI)) {
+                        // the second product of the three-product form has no A^4 term (EXPM3_*[4] = 0); in the first product of
+                        // either form M4 is the launch's own A operand (L2-hot)
+                        const d2 m1 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M1[off])),
+                                 m2 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M2[off])),
+                                 m3 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M3[off]));
+                        const d2 m4 = EPI == EPI_DUAL5 ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(&M4[off]);
+                        if (epi_dual(EPI)) {
+                            d2 w2 = v2;
+                            if (EPI == EPI_DUAL5) {
+                                const d2 m5 = *reinterpret_cast<const d2*>(&M5[off]);  // this launch's A operand
+                                w2 += e5 * m5;
+                                v2 += c5 * m5;
+                            }
+                            w2 += e1 * m1 + e2 * m2 + e3 * m3 + e4 * m4;
+                            if (row == col) w2.x += e0;
+                            if (row + 1 == col) w2.y += e0;
+                            __builtin_nontemporal_store(w2, reinterpret_cast<d2*>(&Cb2[off]));
+                        }
+                        v2 += c1 * m1 + c2 * m2 + c3 * m3 + c4 * m4;  // streamed once per stage
+                        if (row == col) v2.x += c0;
+                        if (row + 1 == col) v2.y += c0;
+                    }
+                    if ((EPI == EPI_SQUARE || EPI == EPI_HORNER) && to_slab) {
+                        if (col < a.Bi.n) {  // slab columns are only 8-byte aligned; never re-read by the engine
+                            if (row + 1 < a.Bi.n) __builtin_nontemporal_store(d2u{-v2.x, -v2.y}, reinterpret_cast<d2u*>(&a.vals[slab_base + row]));
+                            else if (row < a.Bi.n) __builtin_nontemporal_store(-v2.x, &a.vals[slab_base + row]);
+                        }
+                        continue;
+                    }
+                    __builtin_nontemporal_store(v2, reinterpret_cast<d2*>(&Cb[off]));  // 1 GB per launch: gone from L2 before its reader starts
+                }
+                if (epi_dual(EPI)) __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later columns from piling up (spills)
+            }
+    }
+}
+
 static int bgemm_shape_choice() {
     static int v = tune_int("DTO_BGEMM_SHAPE", -1);
     return v;
@@ -652,6 +780,19 @@ static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_c
     }
     hipLaunchKernelGGL((k_bgemm<Cfg, EPI, false>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
 }
+// paired-rows core: persistent for the plain products and the squarings (A by DMA), one workgroup per tile for the
+// polynomial products (their epilogues stream 3-4 more matrices; A through registers), as measured for the 8-byte core
+template <class Cfg, int EPI>
+static void launch_bgemm_p(hipStream_t st, const BGemmArgs& a) {
+    int grid = batch_tile_count(a.nbatch, (a.npad / Cfg::TM) * (a.npad / Cfg::TN));
+    int wgs = bgemm_wgs_choice();
+    if (wgs < 0) wgs = epi_poly(EPI) ? 0 : 2;
+    if (wgs > 0 && grid > wgs * 256) grid = wgs * 256;
+    int dma = bgemm_dma_choice();
+    if (dma < 0) dma = epi_poly(EPI) ? 0 : 1;
+    if (dma) hipLaunchKernelGGL((k_bgemm_p<Cfg, EPI, true>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+    else hipLaunchKernelGGL((k_bgemm_p<Cfg, EPI, false>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+}
 template <int EPI>
 static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
     // 128x128 tiles (persistent, DMA-staged) win once the launch is large; short trajectories are better served by four
@@ -662,6 +803,13 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
     const bool small_launch = force64 >= 0 ? force64 != 0 : t128 * t128 * t128 * a.nbatch < 3500;
     if (a.npad % 128 == 0 && small_launch && bgemm_shape_choice() < 0) {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
+        return;
+    }
+    static const int core = tune_int("DTO_BGEMM_CORE", 1);  // 1: paired-rows core (round 3), 0: the 8-byte core
+    if (a.npad % 128 == 0 && core == 1 && bgemm_shape_choice() < 0) {
+        static const int w8 = tune_int("DTO_BGEMM_P_WAVES8", -1);  // -1: 8 waves for the polynomial epilogues only
+        if (w8 > 0 || (w8 < 0 && epi_poly(EPI))) launch_bgemm_p<GemmShapeP<128, 128, 2, 4>, EPI>(st, a);
+        else launch_bgemm_p<GemmShapeP<128, 128, 2, 2>, EPI>(st, a);
         return;
     }
     if (a.npad % 256 == 0) {
@@ -720,6 +868,9 @@ void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, i
     BGemmArgs a{};
     a.A = w.W[src]; a.B = w.W[src]; a.C = w.W[dst]; a.npad = npad; a.nbatch = nb;
     a.s = w.s; a.it = it; a.P = P; a.Bi = B; a.int0 = int0; a.vals = vals;
+#ifdef DTO_TUNING
+    if (tune_int("DTO_SQ_PLAIN", 0)) a.it = -1;  // timing experiment (wrong results): the last squaring stores into W like the others
+#endif
     launch_bgemm<EPI_SQUARE>(st, a);
 }
 

@@ -54,7 +54,7 @@ errs = {}
 
 def padded(vec):
     L = ev.gather_layout(vec)
-    assert L.in_place_all_gather == 1 and L.world == world
+    assert L.in_place_all_gather == int(os.environ["DTO_EXPECT_INPLACE"]) and L.world == world
     buf = torch.full((L.padded_len,), float("nan"), dtype=torch.float64, device=dev)
     return L, buf, buf.data_ptr() + 8 * (L.front_pad + L.own_lo)
 
@@ -115,13 +115,13 @@ print("rank-ok" if ok else "rank-FAILED")
 """
 
 
-def _run(world, states, N):
+def _run(world, states, N, in_place=1):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
         for rank in range(world):
             env = dict(os.environ, DTO_ROOT=root, DTO_RANK=str(rank), DTO_WORLD=str(world), DTO_IDFILE=os.path.join(tmp, "uid"),
-                       DTO_N=str(N), DTO_STATES=str(states), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       DTO_N=str(N), DTO_STATES=str(states), DTO_EXPECT_INPLACE=str(in_place), HSA_ENABLE_IPC_MODE_LEGACY="0",
                        # one device, two RCCL ranks: each process poses as a host of its own and talks over loopback sockets
                        NCCL_HOSTID=f"dto-test-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_DEBUG="WARN")
             procs.append(subprocess.Popen([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -147,4 +147,10 @@ def test_two_rccl_ranks_gather_through_the_c_abi(states, N):
 
 
 def test_three_rccl_ranks():
-    _run(3, 6, 10)
+    _run(3, 6, 12)
+
+
+def test_unequal_knot_counts_take_the_broadcast_form():
+    # 10 knots over 3 ranks = 4 + 3 + 3: the slabs are not equally long, no padded layout exists, and the same entry points
+    # move them with one in-place broadcast per rank
+    _run(3, 6, 10, in_place=0)
