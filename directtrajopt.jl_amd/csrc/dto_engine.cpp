@@ -203,7 +203,8 @@ struct dto_handle {
     double* h_pinned = nullptr;  // [32]: 0-1 bounds, 2-3 chain scalars, 6 sweep stats, 16-23 hump readback
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr, ev_chain = nullptr;
+    hipStream_t stream_rb = nullptr; // the chain's 96-byte readback (evaluation form, squaring counts, hump bound) leaves on this one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr, ev_chain = nullptr, ev_rb = nullptr;
 
     bool reuse = false;          // option reuse_forward_sweep
     double* d_Zcache = nullptr;  // the Z the cached sweeps belong to
@@ -251,6 +252,8 @@ dto_handle::~dto_handle() {
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (stream) (void)hipStreamDestroy(stream);
     if (stream2) (void)hipStreamDestroy(stream2);
+    if (stream_rb) (void)hipStreamDestroy(stream_rb);
+    if (ev_rb) (void)hipEventDestroy(ev_rb);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_stats) (void)hipEventDestroy(ev_stats);
@@ -767,13 +770,15 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         const int nb = (int)std::min<int64_t>(per, nint - c0);
         const int64_t int0 = h->P.kn_lo + c0;
         ChainWork& w = b.chain;
-        launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
         const int nbpad = ((nb + 127) / 128) * 128;
         if (b.use_basis) {
             HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * (size_t)3 * cap * npad, st));
             launch_fill(st, w.norms, (int64_t)nb * 4, INFINITY);  // ||A||_1 is not needed: alpha never exceeds d_2
             double* outs[3] = {w.W[1], w.W[2], w.W[3]};
             double* css[3] = {w.colsum, w.colsum + (size_t)cap * npad, w.colsum + (size_t)2 * cap * npad};
+            // (A_k as a fourth, degree-1 set of the launch below instead of k_build_A's streaming pass: measured slower,
+            // 1.15 against 0.79 + 0.22 ms -- 8000 more tiles with one K panel each)
+            launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
             launch_basis_coef_multi(st, h->P, b.k, 3, b.basis, dZ, int0, nb, nbpad);
             {
                 // A^2, A^3, A^4 in one launch (tiles interleaved: the write-bound sets overlap the MFMA-bound one)
@@ -783,6 +788,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             }
             launch_norm_from_colsum_multi(st, npad, nb, 3, css, w.norms);
         } else {
+            launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
@@ -801,6 +807,21 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         if (env_form == 2 || env_form == 3) want_form = env_form;
         if (h->expm_form == 2 || h->expm_form == 3) want_form = h->expm_form;
         launch_expm_coef(st, nb, w, want_form);
+        // ... and it leaves on a stream of its own right behind k_expm_coef, so the host learns the form while the GPU is still
+        // busy with K's GEMM (0.65 ms at 256 x 2000) and has the products enqueued before that GEMM ends: no bubble
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
+        static const int rb_side = tune_int("DTO_RB_STREAM", 1);  // 0: the readback follows K's GEMM on the call's stream (round 2)
+        hipEvent_t ev_s = h->ev_chain;
+        auto readback = [&](hipStream_t rs) {
+            HIP_CHECK(hipMemcpyAsync(hs, w.smax, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, rs));
+            HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, rs));
+            HIP_CHECK(hipEventRecord(ev_s, rs));
+        };
+        if (rb_side) {
+            HIP_CHECK(hipEventRecord(h->ev_rb, st));
+            HIP_CHECK(hipStreamWaitEvent(h->stream_rb, h->ev_rb, 0));
+            readback(h->stream_rb);
+        }
         if (b.use_basis) {
             launch_basis_coef(st, h->P, b.k, b.basis_all, dZ, int0, nb, nbpad, w.coef);
             ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * b.basis_all.cntpad * nb);
@@ -808,11 +829,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         } else {
             launch_poly_h3(st, npad, nb, w);
         }
-        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
-        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        hipEvent_t ev_s = h->ev_chain;
-        HIP_CHECK(hipEventRecord(ev_s, st));
+        if (!rb_side) readback(st);
         if (c0 == 0 && in_bubble) in_bubble();
         HIP_CHECK(hipEventSynchronize(ev_s));
         const int form = hs[6];
@@ -1574,6 +1591,8 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipSetDevice(h->device));
             HIP_CHECK(hipStreamCreate(&h->stream));
             HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&h->stream_rb, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_rb, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));

@@ -237,9 +237,9 @@ void launch_norm_from_colsum(hipStream_t st, int npad, int nb, const double* col
 }
 struct BasisMulti {
     int nsets;
-    BasisSet bs[3];
-    double* out[3];
-    double* colsum[3];
+    BasisSet bs[4];
+    double* out[4];
+    double* colsum[4];  // null: no column sums for that set
 };
 // Several basis sets in one grid: block -> (set, tile) with the set index fastest, so neighbouring workgroups mix the
 // write-bound sets with the MFMA-bound ones.
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, 2) k_basis_gemm_multi(int npad, 
     double* out = M.out[0];
     double* colsum = M.colsum[0];
 #pragma unroll
-    for (int q = 1; q < 3; ++q)
+    for (int q = 1; q < 4; ++q)
         if (q == which) { bs = M.bs[q]; out = M.out[q]; colsum = M.colsum[q]; }
     const int64_t nn = (int64_t)npad * npad;
     const int row_tiles = (int)(nn / Cfg::TM);
@@ -281,7 +281,7 @@ __global__ void k_basis_coef_multi(KProb P, KBil B, BasisMulti M, const double* 
     const int b = blockIdx.x;
     BasisSet bs = M.bs[0];
 #pragma unroll
-    for (int q = 1; q < 3; ++q)
+    for (int q = 1; q < 4; ++q)
         if (q == (int)blockIdx.y) bs = M.bs[q];
     double* c = bs.coef + (int64_t)b * bs.cntpad;
     if (b >= nb) {
