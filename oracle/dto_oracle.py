@@ -74,6 +74,133 @@ class ClosureIntegrator:
 
 
 @dataclass
+class TimeDependentBilinearIntegrator:
+    """TimeDependentBilinearIntegrator(G, x, u, t, traj; spline_order) --
+    src/integrators/time_dependent_bilinear_integrator.jl:60-132.
+
+    Defect of interval k (the compiled residual, :123-128): x_{k+1} - y(1), where y solves on the normalised interval
+        dy/dtau = G(u(tau), t_k + tau dt_k) (y dt_k),   y(0) = x_k                      (f!, :102-106)
+    with the controls held, u(tau) = u_k (spline_order 0, :85-86), or interpolated linearly to the next knot,
+    u(tau) = u_k + tau (u_{k+1} - u_k) (spline_order 1, :87-92).  The interval's variables are the stacked knot pair
+    zz = [z_k; z_{k+1}] (x_k, u_k, t_k, dt_k from z_k; x_{k+1}, u_{k+1} from z_{k+1}: evaluate! :150-170, eval_jacobian :180-204).
+
+    The closure G(u, t) is the generator family the engine integrates on the device (include/dto_engine.h,
+    DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR):
+        G(u, t) = sum_{j=0..m} ubar_j (G[j] + sum_c phi_c(t) H_c[j]),  ubar_0 = 1,  phi_c = cos(omega_c t) | sin(omega_c t)
+    -- the reference's own test closure `G(a) + 0.1 cos(t) I` (:262-266) is the member mods = [("cos", 1.0, [0.1 I, 0, ...])].
+
+    WHERE THIS RESTATEMENT DEPARTS FROM THE REFERENCE, and why: the reference integrates with adaptive Tsit5 at
+    OrdinaryDiffEq's default tolerances (:126, reltol 1e-3 / abstol 1e-6) and differentiates THROUGH the adaptive solver with
+    ForwardDiff (:178-244), so its own numbers carry an O(1e-3 .. 1e-6) integration error and are not reproducible to fp64
+    precision by any other code.  What is well defined is the ODE.  This oracle integrates it with classical RK4 on `substeps`
+    equal steps -- the scheme the engine's kernel states in its ABI -- and `tdb_flow_reference` integrates the SAME right-hand
+    side with scipy's DOP853 at rtol 1e-12: tests/test_oracle_pinning.py checks that the fixed-step map converges to that
+    solution at fourth order and sits inside the reference's Tsit5 tolerance at the sub-step counts the tests use.
+    Derivatives: complex step for the Jacobian (exact to rounding for this analytic map), Richardson-extrapolated central
+    differences of the complex-step gradient for the Hessian of mu' f (checked against 40-digit mpmath in the same test file);
+    they stand in for ForwardDiff.jacobian! (:180) and ForwardDiff.hessian (:216) of the same map."""
+
+    x_off: int
+    x_dim: int
+    u_off: int
+    u_dim: int
+    t_off: int
+    G: np.ndarray                      # (u_dim+1, n, n)
+    mods: list = field(default_factory=list)   # [(kind "cos"|"sin", omega, H (u_dim+1, n, n))]
+    spline_order: int = 1
+    substeps: int = 32
+    z: int = 0                         # components per knot; set by `bind`
+    dt_idx: int = 0
+
+    kind = "external"                  # generic dense block per interval (_integrators.jl:49-77)
+
+    def bind(self, z, dt_idx):
+        self.z, self.dt_idx = z, dt_idx
+        return self
+
+    def generator(self, u, t):
+        """G(u, t) of the family; works for complex arguments (complex-step differentiation) and for a leading batch axis
+        (u: (..., m), t: (...,)) -> (..., n, n)."""
+        u = np.asarray(u)
+        t = np.asarray(t)
+        ub = np.concatenate([np.ones(u.shape[:-1] + (1,), dtype=np.result_type(u, t)), u], axis=-1)
+        M = np.einsum("...j,jrc->...rc", ub, self.G)
+        for kind, w, Hc in self.mods:
+            phi = np.cos(w * t) if kind == "cos" else np.sin(w * t)
+            M = M + phi[..., None, None] * np.einsum("...j,jrc->...rc", ub, Hc)
+        return M
+
+    def _unpack(self, zz):
+        z, n, m = self.z, self.x_dim, self.u_dim
+        xk, uk = zz[..., self.x_off:self.x_off + n], zz[..., self.u_off:self.u_off + m]
+        tk, dt = zz[..., self.t_off], zz[..., self.dt_idx]
+        xk1, uk1 = zz[..., z + self.x_off:z + self.x_off + n], zz[..., z + self.u_off:z + self.u_off + m]
+        return xk, uk, tk, dt, xk1, uk1
+
+    def rhs(self, zz):
+        """The reference's f! (:102-106) as rhs(tau, y) for the interval whose stacked variables are zz (a leading batch
+        axis of zz and y is carried along)."""
+        xk, uk, tk, dt, xk1, uk1 = self._unpack(zz)
+        if self.spline_order == 0:
+            ctrl = lambda tau: uk                                   # u_fn, :85-86
+        elif self.spline_order == 1:
+            ctrl = lambda tau: uk + tau * (uk1 - uk)                # u_fn, :87-92
+        else:
+            raise ValueError(f"Unsupported spline order: {self.spline_order}")   # :94
+        return lambda tau, y: np.einsum("...rc,...c->...r", self.generator(ctrl(tau), tk + tau * dt), y * dt[..., None])
+
+    def f(self, zz, k=0):
+        """Residual x_{k+1} - y(1) (:123-128) with y(1) from `substeps` classical Runge-Kutta-4 steps.  zz: (2z,) or (B, 2z)."""
+        zz = np.asarray(zz)
+        xk, _, _, _, xk1, _ = self._unpack(zz)
+        rhs = self.rhs(zz)
+        y, h = xk.astype(np.result_type(zz, np.float64)), 1.0 / self.substeps
+        for i in range(self.substeps):
+            tau = i * h
+            k1 = rhs(tau, y)
+            k2 = rhs(tau + 0.5 * h, y + 0.5 * h * k1)
+            k3 = rhs(tau + 0.5 * h, y + 0.5 * h * k2)
+            k4 = rhs(tau + h, y + h * k3)
+            y = y + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        return xk1 - y
+
+    def jac(self, zz, k=0):
+        """d f / d zz, (..., x_dim, 2z): complex step, exact to rounding (stands in for ForwardDiff.jacobian!, :180-204).
+        All 2z directions run as one batch."""
+        zz = np.asarray(zz, dtype=np.float64)
+        nv = zz.shape[-1]
+        zc = np.repeat(zz[..., None, :].astype(np.complex128), nv, axis=-2)   # (..., direction, 2z)
+        zc[..., np.arange(nv), np.arange(nv)] += 1e-30j
+        return np.swapaxes(self.f(zc).imag / 1e-30, -1, -2)
+
+    def hess(self, zz, k, mu):
+        """Hessian of mu' f, (2z, 2z) (stands in for ForwardDiff.hessian, :216-240): central differences of the complex-step
+        gradient at two step sizes, Richardson-extrapolated (error O(h^4), h = 2e-3 relative to max(1, |zz_i|))."""
+        zz = np.asarray(zz, dtype=np.float64)
+        mu = np.asarray(mu, dtype=np.float64)
+        nv = zz.size
+        h = 2e-3 * np.maximum(1.0, np.abs(zz))
+        pts = np.repeat(zz[None, None, :], 4, axis=0).repeat(nv, axis=1)         # (4 offsets, direction i, 2z)
+        for q, c in enumerate((1.0, -1.0, 0.5, -0.5)):
+            pts[q, np.arange(nv), np.arange(nv)] += c * h
+        g = np.einsum("r,qirv->qiv", mu, self.jac(pts))                           # gradients of mu' f at every point
+        d1 = (g[0] - g[1]) / (2.0 * h[:, None])
+        d2 = (g[2] - g[3]) / h[:, None]
+        H = (4.0 * d2 - d1) / 3.0
+        return 0.5 * (H + H.T)
+
+
+def tdb_flow_reference(integ, zz, rtol=1e-12, atol=1e-14):
+    """y(1) of the interval's ODE (time_dependent_bilinear_integrator.jl:102-106, :123-127) by scipy's adaptive DOP853: the
+    solution the reference's Tsit5 approximates to its own tolerances.  Test infrastructure for the convergence check."""
+    from scipy.integrate import solve_ivp
+    zz = np.asarray(zz, dtype=np.float64)
+    xk = integ._unpack(zz)[0]
+    sol = solve_ivp(integ.rhs(zz), (0.0, 1.0), xk, method="DOP853", rtol=rtol, atol=atol)
+    return sol.y[:, -1]
+
+
+@dataclass
 class QuadraticRegularizer:
     """src/objectives/regularizers.jl:38-167."""
 
@@ -993,6 +1120,56 @@ def make_standard_problem(N=10, seed=3, omega=0.1):
         weights=[1.0, 1.0, 1.0, 1.0],
         constraints=[KnotConstraint("norm", [4, 5], 1.0, list(range(2, N)), equality=False)],
         Z0=data.T.reshape(-1).copy())
+
+
+def make_tdb_problem(N=6, n=4, m=2, order=1, seed=5, substeps=16, n_mods=2, with_derivative=False):
+    """A TimeDependentBilinearIntegrator problem on random data: components x[n], u[m], t, dt (+ du[m] and a
+    DerivativeIntegrator(u, du) with `with_derivative`), generator family with `n_mods` carrier terms
+    (cos 1.7 t and sin 0.6 t), QuadraticRegularizer(u)."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, N))
+    u = 0.4 * rng.standard_normal((m, N))
+    t = np.cumsum(np.full(N, 0.3))[None, :]
+    dt = 0.25 + 0.1 * rng.random((1, N))
+    G = rng.standard_normal((m + 1, n, n)) / np.sqrt(n / 4.0)
+    mods = [("cos", 1.7, 0.5 * rng.standard_normal((m + 1, n, n)) / np.sqrt(n / 4.0)),
+            ("sin", 0.6, 0.5 * rng.standard_normal((m + 1, n, n)) / np.sqrt(n / 4.0))][:n_mods]
+    rows = [x, u]
+    z = n + m + 2 + (m if with_derivative else 0)
+    if with_derivative:
+        rows.append(rng.standard_normal((m, N)))
+    rows += [t, dt]
+    data = np.vstack(rows)
+    t_off, dt_idx = z - 2, z - 1
+    integ = [TimeDependentBilinearIntegrator(0, n, n, m, t_off, G, mods, order, substeps).bind(z, dt_idx)]
+    if with_derivative:
+        integ.append(DerivativeIntegrator(n, m, n + m))
+    return Problem(N=N, z=z, dt_idx=dt_idx, integrators=integ, objectives=[QuadraticRegularizer(n, m, np.ones(m))],
+                   Z0=data.T.reshape(-1).copy())
+
+
+def make_tdb_reference_carrier_problem(N=10, seed=4, omega=0.1, substeps=16):
+    """The reference's own TimeDependentBilinearIntegrator test (time_dependent_bilinear_integrator.jl:259-269 with the
+    generator of test/test_utils.jl:113-175, `bilinear_dynamics_and_trajectory(add_time = true)`): Pauli generators,
+    G(a) = omega Gz + a_1 Gx + a_2 Gy, G_td(a, t) = G(a) + 0.1 cos(t) I, components x[4], u[2], du[2], ddu[2], dt, t
+    (t = cumulative times, appended by add_component), spline_order 1 (the constructor's default), dt = 0.1, N = 10.
+    Data are seeded here (the reference's are unseeded rand / randn)."""
+    Gx, Gy, Gz = pauli_generators()
+    G = np.stack([omega * Gz, Gx, Gy])
+    H = np.zeros_like(G)
+    H[0] = 0.1 * np.eye(4)
+    rng = np.random.Generator(np.random.Philox(seed))
+    x = 2 * rng.random((4, N)) - 1
+    u = 0.1 * (2 * rng.random((2, N)) - 1)
+    du = rng.standard_normal((2, N))
+    ddu = rng.standard_normal((2, N))
+    dt = np.full((1, N), 0.1)
+    t = np.concatenate([[0.0], np.cumsum(dt[0])[:-1]])[None, :]   # get_times: t_1 = 0
+    data = np.vstack([x, u, du, ddu, dt, t])
+    integ = [TimeDependentBilinearIntegrator(0, 4, 4, 2, 11, G, [("cos", 1.0, H)], 1, substeps).bind(12, 10),
+             DerivativeIntegrator(4, 2, 6), DerivativeIntegrator(6, 2, 8)]
+    return Problem(N=N, z=12, dt_idx=10, integrators=integ, objectives=[QuadraticRegularizer(4, 2, np.ones(2))],
+                   Z0=data.T.reshape(-1).copy())
 
 
 def make_external_integrator_problem(N=7, seed=9):

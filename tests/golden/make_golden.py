@@ -26,6 +26,12 @@ CASES = {
     "closure_terms_N9": lambda: O.make_closure_problem(),
     "external_integrator_N7": lambda: O.make_external_integrator_problem(),
     "global_terms_N7": lambda: O.make_global_problem(),
+    # TimeDependentBilinearIntegrator (oracle: RK4 restatement of the reference's ODE, pinned against DOP853 at rtol 1e-12 in
+    # tests/test_oracle_pinning.py): controls interpolated / held, the reference's own carrier test, a 16-state case
+    "tdb_modulated_N6": lambda: O.make_tdb_problem(N=6, n=4, m=2, order=1, seed=5, substeps=16),
+    "tdb_modulated_order0_N6": lambda: O.make_tdb_problem(N=6, n=4, m=2, order=0, seed=6, substeps=16, with_derivative=True),
+    "tdb_reference_carrier_N10": lambda: O.make_tdb_reference_carrier_problem(),
+    "tdb_n16_N3": lambda: O.make_tdb_problem(N=3, n=16, m=2, order=1, seed=7, substeps=8, n_mods=1),
 }
 
 

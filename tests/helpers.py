@@ -5,13 +5,18 @@ import dto_amd
 import dto_oracle as O
 
 
-def to_engine(prob: O.Problem, closure_derivatives="numeric"):
+def to_engine(prob: O.Problem, closure_derivatives="numeric", tdb_on_device=True):
     """Build NamedTrajectory + DirectTrajOptProblem (host mirror) describing the same problem."""
     N, z = prob.N, prob.z
     data = prob.Z0[:z * N].reshape(N, z).T
     # one trajectory component per distinct range mentioned by the problem; leftovers become filler
     ranges = {}
     for it in prob.integrators:
+        if isinstance(it, O.TimeDependentBilinearIntegrator):
+            ranges[(it.x_off, it.x_dim)] = None
+            ranges[(it.u_off, it.u_dim)] = None
+            ranges[(it.t_off, 1)] = None
+            continue
         if it.kind == "external":
             continue
         ranges[(it.x_off, it.x_dim)] = None
@@ -40,6 +45,14 @@ def to_engine(prob: O.Problem, closure_derivatives="numeric"):
     assert traj.dim == z
     integ = []
     for it in prob.integrators:
+        if isinstance(it, O.TimeDependentBilinearIntegrator):
+            # the DEVICE integrator (csrc/dto_tdb.hip) for the same generator family; `tdb_on_device=False` routes the same
+            # closure through the host-evaluated merge path instead
+            fam = dto_amd.ModulatedGenerators(it.G, it.mods)
+            integ.append(dto_amd.TimeDependentBilinearIntegrator(fam, names[(it.x_off, it.x_dim)], names[(it.u_off, it.u_dim)],
+                                                                 names[(it.t_off, 1)], traj, spline_order=it.spline_order,
+                                                                 substeps=it.substeps, on_device=tdb_on_device))
+            continue
         if it.kind == "external":
             analytic = closure_derivatives == "analytic"
             integ.append(dto_amd.HostIntegrator(it.f, it.x_dim, traj, jac=it.jac if analytic else None,

@@ -301,3 +301,128 @@ def test_time_dependent_bilinear_mirror_reduces_to_the_exponential():
     B1 = dto_amd.TimeDependentBilinearIntegrator(Gt, "x", "u", "t", traj, spline_order=1, substeps=16)
     B2 = dto_amd.TimeDependentBilinearIntegrator(Gt, "x", "u", "t", traj, spline_order=1, substeps=256)
     assert np.allclose(B1.external_blocks(Zk, 0)[0], B2.external_blocks(Zk, 0)[0], atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------
+# TimeDependentBilinearIntegrator (oracle restatement: O.TimeDependentBilinearIntegrator)
+# ----------------------------------------------------------------------------------------------
+
+def _interval(p, k):
+    return np.concatenate([p.Z0[k * p.z:(k + 1) * p.z], p.Z0[(k + 1) * p.z:(k + 2) * p.z]])
+
+
+def test_tdb_fixed_step_map_converges_to_the_ode_solution_on_the_reference_carrier_example():
+    """The reference integrates dy/dtau = G(u(tau), t_k + tau dt_k) (y dt_k) adaptively (Tsit5, default reltol 1e-3 / abstol
+    1e-6, time_dependent_bilinear_integrator.jl:123-128) on its own test closure G(a) + 0.1 cos(t) I (:262-266).  The oracle's
+    fixed-step RK4 map of the same right-hand side converges at fourth order to scipy's DOP853 solution at rtol 1e-12, and at the
+    sub-step counts the tests use it is orders of magnitude inside the reference's own integration tolerance."""
+    p = O.make_tdb_reference_carrier_problem()
+    it = p.integrators[0]
+    for k in (0, 4, 8):
+        zz = _interval(p, k)
+        want = zz[p.z:p.z + 4] - O.tdb_flow_reference(it, zz)
+        errs = []
+        for s in (1, 2, 4, 8, 16):
+            it_s = O.TimeDependentBilinearIntegrator(it.x_off, it.x_dim, it.u_off, it.u_dim, it.t_off, it.G, it.mods,
+                                                     it.spline_order, s).bind(p.z, p.dt_idx)
+            errs.append(np.abs(it_s.f(zz) - want).max())
+        assert errs[2] <= 1e-8 and errs[4] <= 1e-11, errs          # 4 sub-steps already beat Tsit5's abstol by 100x
+        for a, b in zip(errs[:3], errs[1:4]):
+            assert 10.0 <= a / b <= 24.0, errs                        # fourth order: 16x per halving (before rounding)
+
+
+@pytest.mark.parametrize("n,m,order", [(4, 2, 1), (8, 3, 0), (16, 2, 1)])
+def test_tdb_convergence_across_sizes_and_spline_orders(n, m, order):
+    p = O.make_tdb_problem(N=3, n=n, m=m, order=order, seed=31 + n, substeps=8)
+    it = p.integrators[0]
+    zz = _interval(p, 0)
+    want = zz[p.z:p.z + n] - O.tdb_flow_reference(it, zz)
+    errs = []
+    for s in (8, 16, 32, 64):
+        it_s = O.TimeDependentBilinearIntegrator(it.x_off, n, it.u_off, m, it.t_off, it.G, it.mods, order, s).bind(p.z, p.dt_idx)
+        errs.append(np.abs(it_s.f(zz) - want).max() / max(1.0, np.abs(want).max()))
+    assert errs[-1] <= 1e-9 and errs[0] / errs[1] >= 9.0 and errs[1] / errs[2] >= 9.0, errs
+    # spline order 1 really reads u_{k+1}; order 0 does not (time_dependent_bilinear_integrator.jl:85-92)
+    J = it.jac(zz)
+    next_u = np.abs(J[:, p.z + it.u_off:p.z + it.u_off + m]).max()
+    assert (next_u > 1e-4) if order == 1 else (next_u == 0.0)
+    assert np.abs(J[:, it.t_off]).max() > 1e-4                         # the carrier terms make the block depend on t_k
+
+
+def test_tdb_time_independent_family_is_the_matrix_exponential():
+    """No carrier terms, controls held: y(1) = exp(dt G(u)) x_k, the BilinearIntegrator's flow (bilinear_integrator.jl:81)."""
+    rng = np.random.default_rng(3)
+    n, m, z = 3, 1, 6
+    G = 0.7 * rng.standard_normal((m + 1, n, n))
+    it = O.TimeDependentBilinearIntegrator(0, n, n, m, 4, G, [], 0, 200).bind(z, 5)
+    zz = rng.standard_normal(2 * z)
+    zz[5] = 0.2
+    E = sla.expm(0.2 * (G[0] + zz[3] * G[1]))
+    assert np.allclose(it.f(zz), zz[z:z + n] - E @ zz[:n], atol=1e-12)
+    J = it.jac(zz)
+    assert np.allclose(J[:, :n], -E, atol=1e-11) and np.allclose(J[:, z:z + n], np.eye(n), atol=1e-14)
+    assert np.allclose(J[:, 3], -sla.expm_frechet(0.2 * (G[0] + zz[3] * G[1]), 0.2 * G[1], compute_expm=False) @ zz[:n], atol=1e-11)
+
+
+def test_tdb_derivatives_against_40_digit_arithmetic():
+    """Complex-step Jacobian and Richardson-extrapolated Hessian of the oracle against mpmath: the same RK4 map evaluated in
+    40-digit arithmetic and differentiated numerically there (mp.diff), entry by entry."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    rng = np.random.default_rng(12)
+    n, m, z, S = 2, 1, 5, 4
+    G = rng.standard_normal((m + 1, n, n))
+    Hc = 0.5 * rng.standard_normal((m + 1, n, n))
+    it = O.TimeDependentBilinearIntegrator(0, n, n, m, 3, G, [("cos", 1.3, Hc)], 1, S).bind(z, 4)
+    zz = rng.standard_normal(2 * z)
+    zz[4] = 0.3
+    mu = rng.standard_normal(n)
+    Gm = [mp.matrix(G[j].tolist()) for j in range(m + 1)]
+    Hm = [mp.matrix(Hc[j].tolist()) for j in range(m + 1)]
+
+    def gen(u, t):
+        return (Gm[0] + mp.cos(mp.mpf("1.3") * t) * Hm[0]) + u * (Gm[1] + mp.cos(mp.mpf("1.3") * t) * Hm[1])
+
+    def flow(*v):
+        x, uk, tk, dt, uk1 = mp.matrix(v[0:2]), v[2], v[3], v[4], v[z + 2]
+        rhs = lambda tau, y: gen(uk + tau * (uk1 - uk), tk + tau * dt) * (y * dt)
+        y, h = x, mp.mpf(1) / S
+        for i in range(S):
+            tau = i * h
+            k1 = rhs(tau, y)
+            k2 = rhs(tau + h / 2, y + h / 2 * k1)
+            k3 = rhs(tau + h / 2, y + h / 2 * k2)
+            k4 = rhs(tau + h, y + h * k3)
+            y = y + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        return [v[z + i] - y[i] for i in range(n)]
+
+    z0 = tuple(mp.mpf(float(v)) for v in zz)
+    J, H = it.jac(zz), it.hess(zz, 0, mu)
+    for a in range(2 * z):
+        order = [0] * (2 * z)
+        order[a] = 1
+        for i in range(n):
+            ref = mp.diff(lambda *v: flow(*v)[i], z0, tuple(order))
+            assert abs(float(ref) - J[i, a]) <= 1e-13 * max(1.0, abs(float(ref))), (i, a)
+    phi = lambda *v: sum(mp.mpf(float(mu[i])) * flow(*v)[i] for i in range(n))
+    for a in range(2 * z):
+        for b in range(a, 2 * z):
+            order = [0] * (2 * z)
+            order[a] += 1
+            order[b] += 1
+            ref = float(mp.diff(phi, z0, tuple(order)))
+            assert abs(ref - H[a, b]) <= 2e-10 * max(1.0, abs(ref)), (a, b, ref, H[a, b])
+
+
+def test_tdb_passes_the_reference_fd_bars():
+    """test_integrator's finite-difference comparison (src/integrators/_integrators.jl:97-242) at the bar the reference's
+    TimeDependentBilinearIntegrator tests use (atol 1e-3, time_dependent_bilinear_integrator.jl:256, :268)."""
+    p = O.make_tdb_reference_carrier_problem()
+    ev = O.OracleEvaluator(p)
+    Z = p.Z0
+    r, c = ev.jacobian_structure1()
+    J = np.zeros((ev.n_constraints, p.n_vars))
+    J[r - 1, c - 1] = ev.eval_constraint_jacobian(Z)
+    eps = 1e-6
+    Jfd = np.stack([(ev.eval_constraint(Z + eps * e) - ev.eval_constraint(Z - eps * e)) / (2 * eps) for e in np.eye(p.n_vars)], axis=1)
+    assert np.allclose(J, Jfd, atol=1e-3) and np.abs(J - Jfd).max() <= 1e-8
