@@ -154,6 +154,31 @@ def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
             dt = (time.perf_counter() - t0) / 5
             out[name] = {"ms_per_call": dt * 1e3, "knot_points_per_s": N / dt,
                          "finite": bool(torch.isfinite(bufs[name]).all().item())}
+        # the Hessian's own roofline (configs[2] names eval_hessian_lagrangian): its dominant kernel is the adjoint generator
+        # sweep, timed with HIP events in a serial pass (overlap_sweep = 0); the rest of the callback is HBM-bound assembly
+        ev.set_option("overlap_sweep", 0)
+        ev.profile_enable(True)
+        calls["eval_hessian_lagrangian"]()
+        torch.cuda.synchronize(dev)
+        ev.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            calls["eval_hessian_lagrangian"]()
+        torch.cuda.synchronize(dev)
+        dt_serial = (time.perf_counter() - t0) / 5
+        ev.profile_enable(False)
+        ms_a, n_a, fl_a = ev.profile_get("expmv_adjoint")
+        nbytes = 8.0 * (ev.shard.hess_len + Z.numel() + ev.n_constraints + sum(it.G.size for it in prob.integrators if hasattr(it, "G")))
+        h = out["eval_hessian_lagrangian"]
+        if n_a and ms_a > 0:
+            ach = fl_a / (ms_a * 1e-3) / 1e12
+            h["roofline"] = {"bound": "mfma", "kernel": "k_sweep_fused (adjoint generator sweep: exp(A')mu and its u-tangents)",
+                             "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                             "launches": n_a, "avg_launch_ms": ms_a / n_a, "flops_per_launch": fl_a / n_a,
+                             "share_of_call": ms_a / n_a / (dt_serial * 1e3), "ms_per_call_serial_pass": dt_serial * 1e3,
+                             "measured_in": "serial pass (overlap_sweep = 0), HIP events on the launch stream"}
+        h["callback_hbm"] = {"algorithmic_bytes": nbytes, "achieved": nbytes / (h["ms_per_call"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": nbytes / (h["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     finally:
         ev.close()
     return out
@@ -411,9 +436,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the dominant kernel of the callback: the propagator chain's batched GEMM (Jacobian), the adjoint generator sweep (Hessian:
+    # one persistent k_sweep_fused launch, 3.7 of 5.7 ms at 256 x 2000)
+    dominant = "expmv_adjoint" if args.callback == "hessian" else "bgemm"
+
     def collect():
         """HIP-event figures of the engine's kernels since the last profile_reset."""
-        ms_g, n_g, fl_g = ev.profile_get("bgemm")
+        ms_g, n_g, fl_g = ev.profile_get(dominant)
         ms_s, n_s, fl_s = ev.profile_get("expmv")
         var = {}
         for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("basis", "basis")):
@@ -437,11 +466,12 @@ def main():
     # a time, which is also what `rocprofv3 -- python3 bench.py --serial-kernels` shows (profiles/) -- and the timed
     # region's own figures are reported next to it.
     overlapped = None
-    if args.callback == "jacobian" and not args.serial_kernels and not args.no_kernel_timing:
+    if args.callback in ("jacobian", "hessian") and not args.serial_kernels and not args.no_kernel_timing:
         overlapped = {"avg_launch_ms": ms_gemm / max(n_gemm, 1), "launches": n_gemm,
                       "achieved": fl_gemm / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0,
                       "sweep_ms_per_step": ms_sweep / args.steps,
-                      "note": "k_bgemm launches of the timed region: the sweep runs next to them on a second stream"}
+                      "note": ("k_bgemm launches of the timed region: the sweep runs next to them on a second stream" if args.callback == "jacobian"
+                               else "the adjoint sweep of the timed region: the forward sweep of the p column runs next to it on a second stream")}
         ev.set_option("overlap_sweep", 0)
         ev.profile_enable(True)
         step()
@@ -529,7 +559,8 @@ def main():
                        "inputs": "Z and the value slab resident in HBM; the 4.2 MB host-to-device copy of Z that SURVEY.md §8d's "
                                  "metric lists is NOT in `value` (host-pointer figures: DESIGN.md §5)"},
             "roofline": {
-                "bound": "mfma", "kernel": "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)",
+                "bound": "mfma", "kernel": ("k_sweep_fused (adjoint generator sweep of the Hessian: exp(A')mu and its u-tangents, one persistent launch)"
+                                            if args.callback == "hessian" else "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": n_gemm, "avg_launch_ms": ms_gemm / max(n_gemm, 1),

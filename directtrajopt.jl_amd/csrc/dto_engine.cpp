@@ -166,6 +166,10 @@ struct dto_handle {
         int kind, comp_off, comp_dim;
         std::vector<int32_t> comps;
         std::vector<int64_t> times;  // owned, 0-based
+        // The term's listings are stored in LAYERS: layer l holds the (l+1)-th listing of every knot, so that inside one layer
+        // no two listings name the same knot.  Gradient and Hessian kernels run layer by layer (one launch each; a single
+        // layer unless `times` repeats a knot): contributions to one entry are added in listing order, never concurrently.
+        std::vector<int64_t> layer_start;  // [n_layers + 1] offsets into the (layer-sorted) listing arrays
     };
     std::vector<ObjInfo> obj_info;
     // host-pointer entry points: only the entries that can change cross PCIe (dto_hostxfer.h); built lazily at the first
@@ -218,6 +222,7 @@ struct dto_handle {
     int sweep_form = 0;   // option "sweep_form": 0 = fused persistent sweep where it applies, 1 = step-per-launch form only
     int n_cu = 256;
     int chain_chunk = 0;  // option "chain_chunk": upper bound on the intervals per chain chunk (0: workspace capacity)
+    int deterministic = 0;  // option "deterministic": results independent of overlap_sweep and of the entry-point family
     // deferred errors of the `*_dev` entry points (dto_engine.h, error convention): the sweep statistics of the last
     // asynchronous call are copied to pinned memory behind its kernels and looked at by the next call through the ABI
     hipEvent_t ev_done = nullptr;
@@ -300,7 +305,7 @@ struct ProfScope {
         h->prof.push_back(r);
     }
 };
-enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BGEMM_SQUARE = 4 };
+enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BGEMM_SQUARE = 4, CAT_SWEEP_ADJOINT = 5 };
 
 // ------------------------------------------------------------------------------------------
 // structure
@@ -557,7 +562,7 @@ bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& 
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
               int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false,
-              bool skip_init = false, bool want_steps = false, bool shared_chip = false) {
+              bool skip_init = false, bool want_steps = false, bool shared_chip = false, int prof_cat = CAT_SWEEP) {
     const double flops_step = [&] {
         double segs = 0;
         for (int t = w.frozen ? w.first_type : 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
@@ -578,7 +583,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
         HIP_CHECK(hipMemsetAsync(w.stats, 0, 4 * sizeof(int32_t), st));
         {
             // flops of the step budget (an upper bound: workgroups leave when their columns have converged)
-            ProfScope ps(h, st, CAT_SWEEP, flops_step * plan.d_ub * plan.q);
+            ProfScope ps(h, st, prof_cat, flops_step * plan.d_ub * plan.q);
             HIP_CHECK(launch_sweep_fused(st, h->P, b.k, w, ty, fp, dZ, dmu, src_kind, transposed, plan.q, plan.d_ub, tc, store, 1.1e-16));
         }
         if (!want_steps) return plan.d_ub;
@@ -594,7 +599,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
     // one timed region per sweep (steps, termination tests and the gaps between them): an event pair per step costs
     // 0.2 ms per Jacobian call at 256x2000.  Its flop count covers every enqueued step, including the few that find their
     // column blocks already converged (bench.py prices the sweep by the terms actually used, dto_last_stats).
-    ProfScope ps(h, st, CAT_SWEEP, 0.0);
+    ProfScope ps(h, st, prof_cat, 0.0);
     for (int round = 0; round < plan.q; ++round) {
         if (round > 0) launch_sweep_restart(st, w, ty.T);
         int buf = 0;
@@ -726,7 +731,7 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
     const size_t nn = (size_t)b.k.npad * b.k.npad;
     for (int i = 0; i < 9; ++i) b.chain.W[i] = own(h, dalloc<double>(nn * cap));
     b.chain.norms = own(h, dalloc<double>((size_t)cap * 4));
-    b.chain.colsum = own(h, dalloc<double>((size_t)3 * cap * b.k.npad));
+    b.chain.colsum = own(h, dalloc<double>((size_t)3 * cap * b.k.npad * (b.k.npad / 64)));  // [set][interval][column][64-row chunk]
     if (!b.d_hump) b.d_hump = own(h, dalloc<unsigned long long>(8));
     b.chain.coef = own(h, dalloc<double>((size_t)cap * COEF_STRIDE));
     b.chain.s = own(h, dalloc<int32_t>(cap));
@@ -757,7 +762,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     double d2max = 0.0;
     if (nint <= 0) return d2max;
     int cap = h->chain_chunk > 0 ? std::min(h->chain_chunk, b.chain_cap) : b.chain_cap;
-    if (h->xfer_cap > 0) cap = std::min(cap, h->xfer_cap);
+    if (h->xfer_cap > 0 && !h->deterministic) cap = std::min(cap, h->xfer_cap);
     int s_ub = 1;
     if (b1max == b1max && b1max > THETA_16) s_ub = std::isinf(b1max) ? 60 : std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
     s_ub = std::min(s_ub, 60);
@@ -772,10 +777,10 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         ChainWork& w = b.chain;
         const int nbpad = ((nb + 127) / 128) * 128;
         if (b.use_basis) {
-            HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * (size_t)3 * cap * npad, st));
             launch_fill(st, w.norms, (int64_t)nb * 4, INFINITY);  // ||A||_1 is not needed: alpha never exceeds d_2
             double* outs[3] = {w.W[1], w.W[2], w.W[3]};
-            double* css[3] = {w.colsum, w.colsum + (size_t)cap * npad, w.colsum + (size_t)2 * cap * npad};
+            const size_t cs_set = (size_t)cap * npad * (npad / 64);  // every slot is written by the launch below: no clearing
+            double* css[3] = {w.colsum, w.colsum + cs_set, w.colsum + 2 * cs_set};
             // (A_k as a fourth, degree-1 set of the launch below instead of k_build_A's streaming pass: measured slower,
             // 1.15 against 0.79 + 0.22 ms -- 8000 more tiles with one K panel each)
             launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
@@ -896,9 +901,8 @@ double exact_d2(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, boo
             // written (K = number of degree-2 products: a few GFLOP for all intervals)
             const int nbpad = ((nb + 127) / 128) * 128;
             const int nr = higher ? 3 : 1;
-            HIP_CHECK(hipMemsetAsync(w.colsum, 0, sizeof(double) * ((size_t)(nr - 1) * b.chain_cap + nb) * npad, st));
             for (int r = 0; r < nr; ++r) {
-                double* cs = w.colsum + (size_t)r * b.chain_cap * npad;
+                double* cs = w.colsum + (size_t)r * b.chain_cap * npad * (npad / 64);
                 launch_basis_coef(st, h->P, b.k, b.basis[r], dZ, int0, nb, nbpad, nullptr);
                 launch_basis_gemm(st, npad, nb, nbpad, b.basis[r], nullptr, cs);
                 launch_norm_from_colsum(st, npad, nb, cs, w.norms, 1 + r, higher ? nullptr : w.d2max);
@@ -1002,6 +1006,24 @@ void tdb_eval(dto_handle* h, TdbHost& t, const double* dZ, const double* dmu, in
     HIP_CHECK(launch_tdb(st, P, t.k, dZ, dmu, need, lo, hi - lo, t.d_vals, t.d_jac, t.d_hess, t.d_scratch, t.stride));
 }
 
+// One launch per layer of an objective term's listings (a single layer unless its `times` repeats a knot): within a launch no
+// two listings touch the same gradient / Hessian entry, across launches the stream orders them -- fixed order of addition.
+template <class F>
+void for_layers(dto_handle* h, size_t i, F&& f) {
+    const KObj& o = h->obj[i];
+    const std::vector<int64_t>& ls = h->obj_info[i].layer_start;
+    for (size_t l = 0; l + 1 < ls.size(); ++l) {
+        KObj ol = o;
+        const int64_t i0 = ls[l];
+        ol.n_times = ls[l + 1] - i0;
+        ol.times += i0;
+        if (ol.Qs) ol.Qs += i0;
+        if (ol.last) ol.last += i0;
+        if (ol.params) ol.params += i0 * ol.n_comps;
+        f(ol);
+    }
+}
+
 void do_objective(dto_handle* h, const double* dZ, double* df, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(df, 0, sizeof(double), st));
     for (auto& o : h->obj) launch_objective(st, h->P, o, dZ, h->d_partial, df);
@@ -1011,7 +1033,8 @@ void do_objective(dto_handle* h, const double* dZ, double* df, hipStream_t st) {
 
 void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st) {
     HIP_CHECK(hipMemsetAsync(dgrad, 0, sizeof(double) * (size_t)h->info.grad_len, st));
-    for (auto& o : h->obj) launch_gradient(st, h->P, o, dZ, dgrad);
+    for (size_t i = 0; i < h->obj.size(); ++i)
+        for_layers(h, i, [&](const KObj& ol) { launch_gradient(st, h->P, ol, dZ, dgrad); });
     for (auto& e : h->ext_obj)
         if (e.k.n_list > 0) launch_ext_gradient(st, h->P, e.k, e.weight, ext_upload(h, e.ext_slot, 1, st), dgrad);
 }
@@ -1107,7 +1130,10 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 }
                 // with reuse on and a Hessian to follow, keep every Taylor term so that the Hessian can skip its forward sweep
                 const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
-                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep, false, false, /*shared_chip=*/overlap);
+                // (option "deterministic": the sweep keeps the shape it has when it runs alone, so the bits do not depend on
+                // overlap_sweep; next to the chain the 256-state sweep otherwise groups its intervals by twelve instead of nine)
+                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep, false, false,
+                                            /*shared_chip=*/overlap && !h->deterministic);
                 launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
@@ -1156,7 +1182,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             if (side_by_side) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ, dmu and the zeroed slab are ready here
                 HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-                run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, true, false, /*want_steps=*/false);
+                run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, true, false, /*want_steps=*/false, false, CAT_SWEEP_ADJOINT);
                 adjoint_enqueued = true;
             }
             hipStream_t sf = side_by_side ? h->stream2 : st;
@@ -1190,7 +1216,15 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 launch_apply_generators(st, b.k, b.ad, 1, b.ad.Z[0], b.ad.W);
             }
             const int steps_a = adjoint_enqueued ? fused_sweep_steps(h, b.ad, plan.d_ub, st)
-                                                 : run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair, false, /*want_steps=*/pair);
+                                                 : run_sweep(h, b, b.ad, ty1, dZ, dmu, 1, 1, plan, st, pair, false, /*want_steps=*/pair, false, CAT_SWEEP_ADJOINT);
+            if (h->profiling && pair)
+                // the fused launch was priced by its step budget; now that the terms it ran are known, price it by those: 2 npad^2
+                // (m+1) generator products per column and term, (1+m) column types (the flops bench.py's roofline uses)
+                for (auto it = h->prof.rbegin(); it != h->prof.rend(); ++it)
+                    if (it->cat == CAT_SWEEP_ADJOINT) {
+                        if (it->flops > 0.0) it->flops = 2.0 * b.k.npad * (double)b.k.npad * b.ad.Kpad * (m + 1) * T1 * steps_a * plan.q;
+                        break;
+                    }
             launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
             launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
             if (pair) {
@@ -1225,7 +1259,8 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             launch_ext_hess(st, h->P, c.xk, 1.0, ext_upload(h, c.ext_slot, 2, st), dH);
     }
     if (sigma != 0.0) {
-        for (auto& o : h->obj) launch_hess_objective(st, h->P, o, dZ, sigma, dH);
+        for (size_t i = 0; i < h->obj.size(); ++i)
+            for_layers(h, i, [&](const KObj& ol) { launch_hess_objective(st, h->P, ol, dZ, sigma, dH); });
         for (auto& e : h->ext_obj)
             if (e.k.n_list > 0) launch_ext_hess(st, h->P, e.k, sigma * e.weight, ext_upload(h, e.ext_slot, 2, st), dH);
     }
@@ -1431,8 +1466,11 @@ void enqueue_stats(dto_handle* h, hipStream_t st) {
     h->stats_pending = true;
 }
 // Look at the statistics of the last call (waits for them): a sweep that ran out of its step budget is an error.
-void check_sweeps(dto_handle* h) {
+void check_sweeps(dto_handle* h, bool wait = true) {
     if (!h->stats_pending) return;
+    // a call that runs no sweep of its own (objective, gradient) does not wait for the previous asynchronous call: it looks
+    // only if that call has finished, and otherwise leaves the check to the next call that would overwrite the statistics
+    if (!wait && hipEventQuery(h->ev_done) != hipSuccess) { (void)hipGetLastError(); return; }
     h->stats_pending = false;
     HIP_CHECK(hipEventSynchronize(h->ev_done));
     size_t i = 0;
@@ -1460,7 +1498,7 @@ int guarded(dto_handle* h, F&& f, int mode = G_PLAIN, hipStream_t st = nullptr) 
     if (h->structure_only) return fail(h, "structure-only handle (created with device < 0): no evaluation without a GPU");
     try {
         HIP_CHECK(hipSetDevice(h->device));
-        check_sweeps(h);            // deferred error of the previous asynchronous call, if any
+        check_sweeps(h, mode != G_PLAIN);  // deferred error of the previous asynchronous call, if any
         (void)hipGetLastError();    // the launches below are judged on their own
         f();
         // kernel launches report a rejected configuration through the runtime's last-error slot, not a return value
@@ -1908,9 +1946,32 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             KObj o{};
             o.kind = s.kind; o.weight = s.weight; o.D = s.D;
             std::vector<int64_t> times;
+            std::vector<int64_t> layer_start;
+            // stable order of the listings by layer (occurrence index of their knot); returns the permutation
+            auto layer_order = [&](const std::vector<int64_t>& t) {
+                std::map<int64_t, int> seen;
+                std::vector<int> layer(t.size());
+                int nl = 0;
+                for (size_t q = 0; q < t.size(); ++q) { layer[q] = seen[t[q]]++; nl = std::max(nl, layer[q] + 1); }
+                std::vector<size_t> perm(t.size());
+                for (size_t q = 0; q < perm.size(); ++q) perm[q] = q;
+                std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b2) { return layer[a] < layer[b2]; });
+                layer_start.assign((size_t)nl + 1, 0);
+                for (size_t q = 0; q < t.size(); ++q) layer_start[(size_t)layer[q] + 1]++;
+                for (int l = 0; l < nl; ++l) layer_start[(size_t)l + 1] += layer_start[(size_t)l];
+                if (t.empty()) layer_start.assign(1, 0);
+                return perm;
+            };
+            auto permute = [&](auto& v, const std::vector<size_t>& perm, size_t width) {
+                if (v.empty()) return;
+                auto src = v;
+                for (size_t q = 0; q < perm.size(); ++q)
+                    for (size_t c = 0; c < width; ++c) v[q * width + c] = src[perm[q] * width + c];
+            };
             if (s.kind == DTO_OBJECTIVE_MINIMUM_TIME) {
                 for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn)
                     if (kn < h->K) times.push_back(kn);
+                (void)layer_order(times);
             } else if (s.kind == DTO_OBJECTIVE_QUADRATIC_REGULARIZER || s.kind == DTO_OBJECTIVE_LINEAR_REGULARIZER) {
                 if (s.comp_dim < 1 || s.comp_off < 0 || s.comp_off + s.comp_dim > d->z || !s.R)
                     throw HipError{"objective: bad component range"};
@@ -1929,6 +1990,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 } else {
                     for (int64_t kn = P.kn_lo; kn < P.kn_lo + P.n_knots; ++kn) times.push_back(kn);
                 }
+                permute(times, layer_order(times), 1);
             } else if (s.kind == DTO_OBJECTIVE_KNOT_SQDIST || s.kind == DTO_OBJECTIVE_KNOT_LOWRANK_INFIDELITY) {
                 if (s.n_comps < 1 || !s.comps || !s.times) throw HipError{"knot objective: comps and times are required"};
                 if (s.kind == DTO_OBJECTIVE_KNOT_LOWRANK_INFIDELITY) {
@@ -1953,6 +2015,13 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                         if (s.times[t2] == s.times[t]) { is_last = 0; break; }
                     last.push_back(is_last);
                 }
+                {
+                    const std::vector<size_t> perm = layer_order(times);
+                    permute(times, perm, 1);
+                    permute(Qs, perm, 1);
+                    permute(last, perm, 1);
+                    permute(params, perm, (size_t)s.n_comps);
+                }
                 o.n_comps = s.n_comps;
                 o.comps = own(h, dupload(comps));
                 o.Qs = own(h, dupload(Qs));
@@ -1967,6 +2036,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             o.times = own(h, dupload(times));
             h->obj.push_back(o);
             dto_handle::ObjInfo oi;
+            oi.layer_start = layer_start;
             oi.kind = s.kind; oi.comp_off = s.comp_off; oi.comp_dim = s.comp_dim; oi.times = times;
             if (s.comps && s.n_comps > 0) oi.comps.assign(s.comps, s.comps + s.n_comps);
             h->obj_info.push_back(std::move(oi));
@@ -2564,6 +2634,11 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
         h->P.debug_bad_launch = value != 0;
         return 0;
     }
+    if (std::string(name) == "deterministic") {
+        h->deterministic = value != 0;
+        drop_caches(h);
+        return 0;
+    }
     if (std::string(name) == "expm_form") {
         if (value != 0 && value != 2 && value != 3) return fail(h, "dto_set_option: expm_form takes 0 (by cost), 2 or 3");
         h->expm_form = (int)value;
@@ -2601,6 +2676,7 @@ int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launch
         else if (!strcmp(name, "bgemm_plain")) cat = CAT_BGEMM;
         else if (!strcmp(name, "basis")) cat = CAT_OTHER;
         else if (!strcmp(name, "expmv")) cat = CAT_SWEEP;
+        else if (!strcmp(name, "expmv_adjoint")) cat = CAT_SWEEP_ADJOINT;
         else if (strcmp(name, "all")) throw HipError{"dto_profile_get: unknown name"};
         double tot = 0, fl = 0;
         int64_t n = 0;

@@ -152,7 +152,7 @@ struct SweepTypes {
 struct ChainWork {   // per-chunk workspace of the propagator chain: C matrices npad x npad each
     double* W[9];    // A, A2, A3, A4, then Y+Pa / squaring ping, K / polynomial / squaring pong, Y+Pb, L, R
     double* norms;   // [C][4]
-    double* colsum;  // [3][C][npad] column abs-sums of A^2..A^4 (basis path)
+    double* colsum;  // [3][C][npad][npad/64] column abs-sums of A^2..A^4 per 64-row chunk (basis path; added in fixed order)
     double* coef;    // [C][COEF_STRIDE]
     int32_t* s;      // [C] squarings per interval (of the evaluation form in use)
     int32_t* s3;     // [C] squarings per interval with the three-product form

@@ -141,9 +141,12 @@ void launch_basis_coef(hipStream_t st, const KProb& P, const KBil& B, const Basi
     hipLaunchKernelGGL(k_basis_coef, dim3(nbpad), dim3(128), 0, st, P, B, bs, dZ, int0, nb, taylor);
 }
 
-// Epilogue shared by the generator-subspace GEMMs: store the tile (out may be null: norms only) and accumulate the column
-// abs-sums.  A wave's 64 rows lie inside ONE column of the npad x npad matrix (npad multiple of 64 and of the wave tile), so
-// the 16 lanes that share an interval reduce among themselves and issue one atomic per (interval, matrix column).
+// Epilogue shared by the generator-subspace GEMMs: store the tile (out may be null: norms only) and leave the column
+// abs-sums.  A wave's 64 rows are ONE 64-row chunk of one column of the npad x npad matrix (npad multiple of 64 and of the
+// wave tile): the 16 lanes that share an interval reduce among themselves and STORE the chunk's partial sum --
+// colsum[interval][matrix column][chunk], every slot written exactly once per launch; k_norm_from_colsum* adds the chunks in
+// a fixed order.  (Up to round 2 the chunks met in one slot by atomicAdd: the 1-norms, and with them the squaring counts and
+// the evaluation form at a boundary, depended on the order the waves arrived in.)
 template <class Cfg>
 __device__ __forceinline__ void basis_epilogue(const GemmAccS<Cfg>& acc, int npad, int nb, int rt, int ct, double* __restrict__ out,
                                                double* __restrict__ colsum) {
@@ -169,7 +172,7 @@ __device__ __forceinline__ void basis_epilogue(const GemmAccS<Cfg>& acc, int npa
                 if (colsum) {
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
-                    if ((threadIdx.x & 15) == 0 && col < nb) atomicAdd(&colsum[(int64_t)col * npad + wave_row0 / npad], asum);
+                    if ((threadIdx.x & 15) == 0 && col < nb) colsum[((int64_t)col * npad + wave_row0 / npad) * (npad / 64) + (wave_row0 % npad) / 64] = asum;
                 }
             }
     } else {
@@ -189,7 +192,7 @@ __device__ __forceinline__ void basis_epilogue(const GemmAccS<Cfg>& acc, int npa
                 if (colsum) {
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
-                    if ((threadIdx.x & 15) == 0 && col < nb) atomicAdd(&colsum[(int64_t)col * npad + wave_row0 / npad], asum);
+                    if ((threadIdx.x & 15) == 0 && col < nb) colsum[((int64_t)col * npad + wave_row0 / npad) * (npad / 64) + (wave_row0 % npad) / 64] = asum;
                 }
             }
     }
@@ -219,11 +222,17 @@ __global__ void k_norm_from_colsum(int npad, int nb, const double* __restrict__ 
                                    unsigned long long* d2max) {
     const int b = blockIdx.x;
     double m = 0.0;
-    for (int c = threadIdx.x; c < npad; c += 64) m = fmax(m, colsum[(int64_t)b * npad + c]);
+    const int nch = npad / 64;
+    auto colsum_of = [&](int c) {  // the chunks of one matrix column, added in a fixed order
+        double v = 0.0;
+        for (int q = 0; q < nch; ++q) v += colsum[((int64_t)b * npad + c) * nch + q];
+        return v;
+    };
+    for (int c = threadIdx.x; c < npad; c += 64) m = fmax(m, colsum_of(c));
     m = wave_max(m);
     // NaN anywhere in the matrix must reach the scaling decision (fmax drops it)
     double bad = 0.0;
-    for (int c = threadIdx.x; c < npad; c += 64) { const double v = colsum[(int64_t)b * npad + c]; if (!(v == v)) bad = 1.0; }
+    for (int c = threadIdx.x; c < npad; c += 64) { const double v = colsum_of(c); if (!(v == v)) bad = 1.0; }
     bad = wave_max(bad);
     if (threadIdx.x == 0) {
         const double v = bad > 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : m;
@@ -317,8 +326,10 @@ __global__ void k_norm_from_colsum_multi(int npad, int nb, BasisMulti M, double*
     for (int q = 1; q < 3; ++q)
         if (q == which) colsum = M.colsum[q];
     double m = 0.0, bad = 0.0;
+    const int nch = npad / 64;
     for (int c = threadIdx.x; c < npad; c += 64) {
-        const double v = colsum[(int64_t)b * npad + c];
+        double v = 0.0;
+        for (int q = 0; q < nch; ++q) v += colsum[((int64_t)b * npad + c) * nch + q];  // fixed order
         m = fmax(m, v);
         if (!(v == v)) bad = 1.0;  // NaN anywhere in the matrix must reach the scaling decision (fmax drops it)
     }
@@ -2195,15 +2206,32 @@ __global__ void k_ext_hess(KProb P, KExtTerm E, double scale, const double* __re
     if (v == 0.0) return;
     if (b < E.nc) {  // knot column: both indices in knot times[ti]
         if (E.knot_on[ti]) atomicAdd(&H[hess_pos(P, E.times[ti], E.comps[a], E.comps[b])], v);
-    } else if (E.glob_on) {
+    } else if (E.glob_on && a < E.nc) {  // (knot row, global column): one listing per entry; (global, global): k_ext_hess_glob
         const int64_t p = hess_pos_tail(P, R, E.gcomps[b - E.nc]);
         if (p >= 0) atomicAdd(&H[p], v);
     }
+}
+// Entries whose row AND column are global variables receive a contribution from EVERY listing of the term
+// (global_objectives.jl:270-271, :341 accumulate): one thread per entry adds them in listing order -- no atomics, fixed order.
+__global__ void k_ext_hess_glob(KProb P, KExtTerm E, double scale, const double* __restrict__ blocks, double* __restrict__ H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E.ng * E.ng || !E.glob_on) return;
+    const int gb = i / E.ng, ga = i % E.ng, nb = E.nc + E.ng, nb2 = nb * nb;
+    const int64_t R = P.N * P.z + E.gcomps[ga], C = P.N * P.z + E.gcomps[gb];
+    if (R > C) return;
+    const int64_t p = hess_pos_tail(P, R, E.gcomps[gb]);
+    if (p < 0) return;
+    double s = 0.0;
+    for (int64_t ti = 0; ti < E.n_list; ++ti) s += scale * blocks[E.tidx[ti] * nb2 + (int64_t)(E.nc + gb) * nb + (E.nc + ga)];
+    // two block elements can name the same pair of global variables (a component listed twice): those meet here
+    if (s != 0.0) atomicAdd(&H[p], s);
 }
 void launch_ext_hess(hipStream_t st, const KProb& P, const KExtTerm& E, double scale, const double* blocks, double* H) {
     const int64_t nb = E.nc + E.ng, n = E.n_list * nb * nb;
     if (n <= 0) return;
     hipLaunchKernelGGL(k_ext_hess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, E, scale, blocks, H);
+    if (E.ng > 0 && E.glob_on)
+        hipLaunchKernelGGL(k_ext_hess_glob, dim3((unsigned)((E.ng * E.ng + 63) / 64)), dim3(64), 0, st, P, E, scale, blocks, H);
 }
 
 // f += weight * sum of the counted listings' values, fixed order within the block (deterministic)
@@ -2226,13 +2254,24 @@ __global__ void k_ext_gradient(KProb P, KExtTerm E, double weight, const double*
     if (i >= E.n_list * nb) return;
     const int64_t ti = i / nb;
     const int a = (int)(i % nb);
-    if (a < E.nc ? !E.knot_on[ti] : !E.glob_on) return;
+    if (a >= E.nc || !E.knot_on[ti]) return;  // the global part: k_ext_gradient_glob
     atomicAdd(&grad[ext_var(P, E, ti, a) - P.grad_lo], weight * blocks[E.tidx[ti] * nb + a]);
+}
+// gradient entries of the global variables: every listing contributes; one thread per entry, listing order, no atomics
+__global__ void k_ext_gradient_glob(KProb P, KExtTerm E, double weight, const double* __restrict__ blocks, double* __restrict__ grad) {
+    const int ga = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ga >= E.ng || !E.glob_on) return;
+    const int nb = E.nc + E.ng;
+    double s = 0.0;
+    for (int64_t ti = 0; ti < E.n_list; ++ti) s += weight * blocks[E.tidx[ti] * nb + E.nc + ga];
+    atomicAdd(&grad[P.N * P.z + E.gcomps[ga] - P.grad_lo], s);
 }
 void launch_ext_gradient(hipStream_t st, const KProb& P, const KExtTerm& E, double weight, const double* blocks, double* grad) {
     const int64_t n = E.n_list * (E.nc + E.ng);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_ext_gradient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, E, weight, blocks, grad);
+    if (E.ng > 0 && E.glob_on)
+        hipLaunchKernelGGL(k_ext_gradient_glob, dim3((unsigned)((E.ng + 63) / 64)), dim3(64), 0, st, P, E, weight, blocks, grad);
 }
 
 // Bilinear block of mu_k' f  (bilinear_integrator.jl:135-161).  With y = exp(A)x, c_j = dexp(A)[dt G_j]x,

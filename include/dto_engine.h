@@ -333,6 +333,16 @@ int dto_allreduce_objective_dev(dto_handle* h, double* df, void* stream);
  *   chain (what a 16000-knot trajectory does by itself; tests use it to exercise the chunk loop on small problems).
  *   "debug_bad_launch" (default 0): tests of the error convention -- 1 gives the next callbacks' kernels an invalid launch
  *   configuration, which must come back as a non-zero return code with text. */
+/*   "deterministic" (default 0).  Run to run the engine is bit-reproducible without any option: every reduction has a fixed
+ *   order (column sums of the generator-subspace GEMMs per 64-row chunk, objective partial sums, listings of a term that
+ *   repeats a knot layer by layer, contributions to global-variable entries in listing order; the sweeps' K order is a function
+ *   of the block index).  What still depends on HOW a result is asked for is switched off by 1: the Jacobian's sweep keeps the
+ *   interval grouping it has alone on the chip (else `overlap_sweep` changes the summation order at 256 states), and the
+ *   host-pointer dto_eval_jacobian runs the propagator chain in the same chunks as dto_eval_jacobian_dev (else the early
+ *   hand-over of -E_k caps the chunk, and the evaluation form is decided per chunk).  Cost at 256 x 2000: +0.1..0.4 ms per
+ *   device-resident Jacobian, and the host-pointer Jacobian loses the overlap of its PCIe copy with the chain (23 -> 34 ms).
+ *   Not covered: dto_eval_jacobian_product / _transpose_product (floating-point atomics over rows shared by several
+ *   integrators). */
 int dto_set_option(dto_handle* h, const char* name, int64_t value);
 
 /* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */
@@ -340,7 +350,8 @@ int dto_profile_enable(dto_handle* h, int32_t on);
 int dto_profile_reset(dto_handle* h);
 /* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain: every template instance), its parts
  * "bgemm_horner" (the products with a fused polynomial epilogue) / "bgemm_square" / "bgemm_plain", "basis"
- * (generator-subspace GEMM), "expmv" (sweep step), "all".
+ * (generator-subspace GEMM), "expmv" (forward generator sweeps and the pairing products), "expmv_adjoint" (the Hessian's adjoint
+ * sweep: its dominant kernel), "all".
  * Returns accumulated device milliseconds, launches and algorithmic FLOPs of those launches. */
 int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops);
 /* diagnostics of the last Jacobian call: max squarings used, Taylor terms used by the tangent sweep */
