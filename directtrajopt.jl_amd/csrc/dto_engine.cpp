@@ -1009,10 +1009,10 @@ void tdb_eval(dto_handle* h, TdbHost& t, const double* dZ, const double* dmu, in
 // One launch per layer of an objective term's listings (a single layer unless its `times` repeats a knot): within a launch no
 // two listings touch the same gradient / Hessian entry, across launches the stream orders them -- fixed order of addition.
 template <class F>
-void for_layers(dto_handle* h, size_t i, F&& f) {
+void for_layers(dto_handle* h, size_t i, F&& f, bool first_only = false) {
     const KObj& o = h->obj[i];
     const std::vector<int64_t>& ls = h->obj_info[i].layer_start;
-    for (size_t l = 0; l + 1 < ls.size(); ++l) {
+    for (size_t l = 0; l + 1 < ls.size() && !(first_only && l > 0); ++l) {
         KObj ol = o;
         const int64_t i0 = ls[l];
         ol.n_times = ls[l + 1] - i0;
@@ -1259,8 +1259,12 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             launch_ext_hess(st, h->P, c.xk, 1.0, ext_upload(h, c.ext_slot, 2, st), dH);
     }
     if (sigma != 0.0) {
-        for (size_t i = 0; i < h->obj.size(); ++i)
-            for_layers(h, i, [&](const KObj& ol) { launch_hess_objective(st, h->P, ol, dZ, sigma, dH); });
+        // get_full_hessian of the regularizers ASSIGNS its blocks per listed time (regularizers.jl:155-163, :305-309), so a knot
+        // listed twice counts once -- unlike their value and gradient, which add per listing (:86-87, :102-108): first layer only
+        for (size_t i = 0; i < h->obj.size(); ++i) {
+            const bool assigns = h->obj[i].kind == DTO_OBJECTIVE_QUADRATIC_REGULARIZER || h->obj[i].kind == DTO_OBJECTIVE_LINEAR_REGULARIZER;
+            for_layers(h, i, [&](const KObj& ol) { launch_hess_objective(st, h->P, ol, dZ, sigma, dH); }, assigns);
+        }
         for (auto& e : h->ext_obj)
             if (e.k.n_list > 0) launch_ext_hess(st, h->P, e.k, sigma * e.weight, ext_upload(h, e.ext_slot, 2, st), dH);
     }
