@@ -180,6 +180,7 @@ struct dto_handle {
     std::function<void(int64_t, int)> on_chain_chunk;         // ... and its hook: (first local interval, count) of a finished chunk
     bool plans_built = false;
     int host_xfer = 1;
+    int xfer_check = 0;  // option "host_xfer_check": every host-pointer Jacobian / Hessian is compared with the whole device slab
     std::vector<ExtObjHost> ext_obj;
     std::vector<KExtInt> ext_int;  // DTO_INTEGRATOR_EXTERNAL, slot = index
     std::vector<TdbHost> tdb;      // DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR
@@ -1592,6 +1593,21 @@ int comm_guarded(dto_handle* h, F&& f, bool needs_device = true) {
     }
 }
 
+// Option "host_xfer_check": the hand-off plans (build_jac_plan / build_hess_plan) are a second statement of which slab entries
+// a callback may write; a kernel that writes outside them would be dropped silently on the host-pointer path.  With the
+// option on, every such call also copies the WHOLE device slab and compares it bit for bit with what was assembled.
+void check_against_slab(dto_handle* h, const double* d_slab, const double* assembled, size_t n, const char* what) {
+    std::vector<double> full(n);
+    HIP_CHECK(hipMemcpy(full.data(), d_slab, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (memcmp(full.data(), assembled, n * sizeof(double)) == 0) return;
+    size_t i = 0;
+    while (i < n && memcmp(&full[i], &assembled[i], sizeof(double)) == 0) ++i;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "host_xfer_check: %s entry %zu is %.17g on the device and %.17g in the caller's vector -- a kernel "
+             "wrote outside the hand-off plan", what, i, full[i], assembled[i]);
+    throw HipError{buf};
+}
+
 void upload_Z(dto_handle* h, const double* Z) {
     HIP_CHECK(hipMemcpyAsync(h->d_Z, Z, sizeof(double) * (size_t)h->n_vars, hipMemcpyHostToDevice, h->stream));
 }
@@ -2382,6 +2398,7 @@ int dto_eval_jacobian(dto_handle* h, const double* Z, double* vals) {
                 h->xfer->abort();  // joins the host threads before the error leaves
                 throw;
             }
+            if (h->xfer_check) check_against_slab(h, o, vals, (size_t)h->info.jac_len, "Jacobian");
             return;
         }
         do_jacobian(h, h->d_Z, o, h->stream);
@@ -2407,6 +2424,7 @@ int dto_eval_hessian(dto_handle* h, const double* Z, double sigma, const double*
                 h->xfer->abort();
                 throw;
             }
+            if (h->xfer_check) check_against_slab(h, o, vals, (size_t)h->info.hess_len, "Hessian");
             return;
         }
         do_hessian(h, h->d_Z, sigma, h->d_mu, o, h->stream);
@@ -2635,7 +2653,15 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (std::string(name) == "debug_bad_launch") {
+#ifdef DTO_TUNING
         h->P.debug_bad_launch = value != 0;
+        return 0;
+#else
+        return fail(h, "dto_set_option: debug_bad_launch exists in TUNING builds only (make TUNING=1: libdto_engine_t.so)");
+#endif
+    }
+    if (std::string(name) == "host_xfer_check") {
+        h->xfer_check = value != 0;
         return 0;
     }
     if (std::string(name) == "deterministic") {

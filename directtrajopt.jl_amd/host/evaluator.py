@@ -64,6 +64,9 @@ class Evaluator:
     ``k_lo..k_hi`` (1-based, inclusive).  Inputs ``Z`` and ``mu`` are always the GLOBAL vectors;
     value outputs are the shard-local slabs described by ``shard`` (whole vectors when unsharded)."""
 
+    # options applied to every new handle (dto_set_option name -> value); the repository's tests switch "host_xfer_check" on here
+    default_options = {}
+
     def __init__(self, prob, eval_hessian=True, device=0, k_lo=0, k_hi=0, verbose=False, general_path_only=False):
         self._lib = load_library()
         self._h = capi.H()
@@ -207,6 +210,8 @@ class Evaluator:
         self._lib.dto_hess_nnz(self._h, C.byref(v)); self.n_hessian_entries = v.value
         self.shard = capi.ShardInfo()
         self._lib.dto_get_shard_info(self._h, C.byref(self.shard))
+        for name, value in self.default_options.items():
+            self.set_option(name, value)
 
     # ---- plumbing
     def _check(self, rc):

@@ -331,8 +331,12 @@ int dto_allreduce_objective_dev(dto_handle* h, double* df, void* stream);
  *   launch per Taylor step.
  *   "chain_chunk" (default 0 = the engine's workspace budget): at most this many intervals per chunk of the propagator
  *   chain (what a 16000-knot trajectory does by itself; tests use it to exercise the chunk loop on small problems).
- *   "debug_bad_launch" (default 0): tests of the error convention -- 1 gives the next callbacks' kernels an invalid launch
- *   configuration, which must come back as a non-zero return code with text. */
+ *   "host_xfer_check" (default 0): every host-pointer dto_eval_jacobian / dto_eval_hessian also copies the whole device slab and
+ *   compares it bit for bit with the vector it assembled from the variable runs and the constants; a difference (a kernel that
+ *   wrote an entry the hand-off plan does not list) fails the call.  The repository's GPU tests run with it on.
+ *   "debug_bad_launch": TUNING builds only (libdto_engine_t.so) -- 1 gives the next callbacks' kernels an invalid launch
+ *   configuration, which must come back as a non-zero return code with text (test of the error convention); the product
+ *   library refuses the name. */
 /*   "deterministic" (default 0).  Run to run the engine is bit-reproducible without any option: every reduction has a fixed
  *   order (column sums of the generator-subspace GEMMs per 64-row chunk, objective partial sums, listings of a term that
  *   repeats a knot layer by layer, contributions to global-variable entries in listing order; the sweeps' K order is a function

@@ -1,4 +1,4 @@
-# DTOEngine.jl -- the reference-side binding of libdto_engine.so (include/dto_engine.h, ABI version 5).
+# DTOEngine.jl -- the reference-side binding of libdto_engine.so (include/dto_engine.h, ABI version 6).
 #
 # Drop this file into DirectTrajOpt.jl (e.g. src/solvers/DTOEngine.jl, `include`d from src/solvers/_solvers.jl) and
 # replace the evaluator at the two swap points:
@@ -11,9 +11,14 @@
 # `n_dynamics_constraints`, `n_nonlinear_constraints`, evaluator.jl:66-98).  Everything the engine implements natively
 # runs on the GPU: BilinearIntegrator, DerivativeIntegrator, QuadraticRegularizer, LinearRegularizer,
 # MinimumTimeObjective, CompositeObjective.  Terms that are Julia closures (KnotPointObjective, NonlinearKnotPoint-
-# Constraint, TimeDependentBilinearIntegrator and other integrators) are evaluated HERE with the reference's own
-# functions (`evaluate!`, `eval_jacobian`, `eval_hessian_of_lagrangian`, `objective_value`, `gradient!`,
-# `get_full_hessian`) and merged by the engine at its precomputed offsets (`dto_set_external`).
+# Constraint, TimeDependentBilinearIntegrator and other integrators, GlobalObjective, GlobalKnotPointObjective,
+# NonlinearGlobalConstraint) are evaluated HERE with the reference's own functions (`evaluate!`, `eval_jacobian`,
+# `eval_hessian_of_lagrangian`, `objective_value`, `gradient!`, `get_full_hessian`, or ForwardDiff on the closure exactly as
+# those functions do) and merged by the engine at its precomputed offsets (`dto_set_external`).
+#
+# Beyond the MOI surface the file binds the device-resident entry points (`*_dev!`: MadNLP GPU mode,
+# src/solvers/madnlp_solver/options.jl:12-16 -- value vectors never cross PCIe) and the engine's multi-GPU collectives
+# (`comm_create!`, `gather_jacobian_dev!` and friends: RCCL over xGMI behind the C ABI).
 #
 # This file cannot be executed in the build environment of the engine (no Julia there); tests/test_julia_shim.py checks
 # its struct layouts and ccall signatures against include/dto_engine.h.
@@ -21,14 +26,15 @@ module DTOEngine
 
 using LinearAlgebra
 using SparseArrays
+using ForwardDiff
 import MathOptInterface as MOI
 using NamedTrajectories
 using TrajectoryIndexingUtils: slice
 using ..Problems: DirectTrajOptProblem
 using ..Integrators: AbstractIntegrator, BilinearIntegrator, DerivativeIntegrator
 using ..Objectives: AbstractObjective, CompositeObjective, NullObjective, QuadraticRegularizer, LinearRegularizer,
-    MinimumTimeObjective, objective_value, gradient!, get_full_hessian
-using ..Constraints: AbstractNonlinearConstraint, NonlinearKnotPointConstraint
+    MinimumTimeObjective, GlobalObjective, GlobalKnotPointObjective, objective_value, gradient!, get_full_hessian
+using ..Constraints: AbstractNonlinearConstraint, NonlinearKnotPointConstraint, NonlinearGlobalConstraint
 using ..CommonInterface: evaluate!, eval_jacobian, eval_hessian_of_lagrangian
 
 const lib = get(ENV, "DTO_ENGINE_LIB", "libdto_engine.so")
@@ -42,7 +48,14 @@ const DTO_OBJECTIVE_QUADRATIC_REGULARIZER = Int32(1)
 const DTO_OBJECTIVE_LINEAR_REGULARIZER = Int32(2)
 const DTO_OBJECTIVE_MINIMUM_TIME = Int32(3)
 const DTO_OBJECTIVE_EXTERNAL_KNOT = Int32(5)
+const DTO_OBJECTIVE_EXTERNAL_GLOBAL = Int32(7)
 const DTO_CONSTRAINT_EXTERNAL = Int32(3)
+const DTO_CONSTRAINT_EXTERNAL_GLOBAL = Int32(4)
+const DTO_COMM_ID_BYTES = Int32(128)
+const DTO_VECTOR_JACOBIAN = Int32(1)
+const DTO_VECTOR_HESSIAN = Int32(2)
+const DTO_VECTOR_GRADIENT = Int32(3)
+const DTO_VECTOR_CONSTRAINT = Int32(4)
 
 # ---- plain-C structs, field for field as in include/dto_engine.h ----------------------------------------------------
 struct IntegratorDesc
@@ -125,6 +138,16 @@ struct ExternalValues
     second::Ptr{Float64}
 end
 
+struct GatherLayout
+    total::Int64
+    padded_len::Int64
+    front_pad::Int64
+    own_lo::Int64
+    own_len::Int64
+    in_place_all_gather::Int32
+    world::Int32
+end
+
 # ---- TimeDependentBilinearIntegrator on the device ------------------------------------------------------------------
 """
 The generator family the engine integrates on the GPU (DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR):
@@ -175,9 +198,10 @@ mutable struct GPUEvaluator <: MOI.AbstractNLPEvaluator
     hessian_structure::Vector{Tuple{Int,Int}}
     # host-evaluated terms, in the engine's slot order: integrators, constraints, objectives
     ext_integrators::Vector{Tuple{AbstractIntegrator,Int}}          # (integrator, first NLP row, 1-based)
-    ext_constraints::Vector{Tuple{NonlinearKnotPointConstraint,Int}} # (constraint, first NLP row, 1-based)
+    ext_constraints::Vector{Tuple{AbstractNonlinearConstraint,Int}}  # (constraint, first NLP row, 1-based)
     ext_objectives::Vector{AbstractObjective}
     ext_comps::Dict{Any,Vector{Int}}                                  # term -> knot-local component indices (1-based)
+    ext_gcomps::Dict{Any,Vector{Int}}                                 # Global* term -> indices into global_data (1-based)
     staging::Vector{Vector{Float64}}                                  # keeps the blocks alive across the ccall
 end
 
@@ -254,6 +278,7 @@ function GPUEvaluator(prob::DirectTrajOptProblem; eval_hessian::Bool = true, dev
     odescs = ObjectiveDesc[]
     ext_objectives = AbstractObjective[]
     ext_comps = Dict{Any,Vector{Int}}()
+    ext_gcomps = Dict{Any,Vector{Int}}()
     null = Ptr{Float64}(C_NULL)
     for (o, w) in flatten(prob.objective)
         if o isa QuadraticRegularizer || o isa LinearRegularizer
@@ -269,6 +294,21 @@ function GPUEvaluator(prob::DirectTrajOptProblem; eval_hessian::Bool = true, dev
             push!(odescs, ObjectiveDesc(DTO_OBJECTIVE_MINIMUM_TIME, Int32(0), Int32(0), Int32(0), w, o.D, null, null,
                                         Ptr{Int64}(C_NULL), 0, Ptr{Int32}(C_NULL), Int32(0), Int32(0), null, null,
                                         Ptr{Int32}(C_NULL), Int32(0), Int32(0)))
+        elseif o isa GlobalObjective || o isa GlobalKnotPointObjective
+            # closures over [z_t[var_names]; global_data[global_names]] (global_objectives.jl:35-350): blocks per listing, the
+            # engine ACCUMULATES them (:270-271, :341); a GlobalObjective is one listing of the global variables alone
+            comps1 = o isa GlobalKnotPointObjective ? vcat([collect(traj.components[n]) for n in o.var_names]...) : Int[]
+            gcomps1 = vcat([collect(traj.global_components[n]) for n in o.global_names]...)
+            comps, gcomps = Int32.(comps1 .- 1), Int32.(gcomps1 .- 1)
+            times = o isa GlobalKnotPointObjective ? Vector{Int64}(o.times) : Int64[]
+            push!(keep, comps, gcomps, times)
+            push!(odescs, ObjectiveDesc(DTO_OBJECTIVE_EXTERNAL_GLOBAL, Int32(0), Int32(0), Int32(0), w, 0.0, null, null,
+                                        isempty(times) ? Ptr{Int64}(C_NULL) : pointer(times), length(times),
+                                        isempty(comps) ? Ptr{Int32}(C_NULL) : pointer(comps), Int32(length(comps)), Int32(0), null, null,
+                                        pointer(gcomps), Int32(length(gcomps)), Int32(0)))
+            push!(ext_objectives, o)
+            ext_comps[o] = comps1
+            ext_gcomps[o] = gcomps1
         elseif hasproperty(o, :var_names) && hasproperty(o, :times)   # KnotPointObjective / TerminalObjective: host closure
             comps1 = vcat([collect(traj.components[n]) for n in o.var_names]...)
             comps = Int32.(comps1 .- 1)
@@ -287,9 +327,25 @@ function GPUEvaluator(prob::DirectTrajOptProblem; eval_hessian::Bool = true, dev
     # nonlinear constraints: rows follow the dynamics (evaluator.jl:219-223); closures -> EXTERNAL with the pattern of the
     # Jacobian at the initial point (evaluator.jl:136)
     cdescs = ConstraintDesc[]
-    ext_constraints = Tuple{NonlinearKnotPointConstraint,Int}[]
+    ext_constraints = Tuple{AbstractNonlinearConstraint,Int}[]
     for con in prob.constraints
         con isa AbstractNonlinearConstraint || continue   # linear constraints go to MOI directly (solve.jl)
+        if con isa NonlinearGlobalConstraint
+            # g(global_data[global_names]) (global_constraint.jl:20-160): patterns from the Jacobian and the Hessian of sum(g)
+            # at the initial point (evaluator.jl:136, :166)
+            gcomps1 = vcat([collect(traj.global_components[n]) for n in con.global_names]...)
+            gcomps = Int32.(gcomps1 .- 1)
+            g0 = Vector{Float64}(traj.global_data[gcomps1])
+            jac0 = vec(Matrix{Float64}(ForwardDiff.jacobian(con.g, g0)))
+            hess0 = vec(Matrix{Float64}(ForwardDiff.hessian(x -> sum(con.g(x)), g0)))
+            push!(keep, gcomps, jac0, hess0)
+            push!(cdescs, ConstraintDesc(DTO_CONSTRAINT_EXTERNAL_GLOBAL, Int32(con.equality), Int32(length(gcomps)), Int32(con.dim),
+                                         pointer(gcomps), 0.0, Ptr{Int64}(C_NULL), 0, pointer(jac0), pointer(hess0)))
+            push!(ext_constraints, (con, row))
+            ext_gcomps[con] = gcomps1
+            row += con.dim
+            continue
+        end
         con isa NonlinearKnotPointConstraint || error("DTOEngine: constraint $(typeof(con)) is not supported")
         comps1 = vcat([collect(traj.components[n]) for n in con.var_names]...)
         comps = Int32.(comps1 .- 1)
@@ -335,7 +391,7 @@ function GPUEvaluator(prob::DirectTrajOptProblem; eval_hessian::Bool = true, dev
     hstruct = structure(c -> (@ccall lib.dto_hess_nnz(handle::Ptr{Cvoid}, c::Ptr{Int64})::Cint),
                         (c, r, k) -> (@ccall lib.dto_hessian_structure(handle::Ptr{Cvoid}, 0::Int64, c::Int64, r::Ptr{Int64}, k::Ptr{Int64})::Cint))
     ev = GPUEvaluator(handle, traj, n_vars, n_cons, n_dyn, n_cons - n_dyn, eval_hessian, jstruct, hstruct,
-                      ext_integrators, ext_constraints, ext_objectives, ext_comps, Vector{Float64}[])
+                      ext_integrators, ext_constraints, ext_objectives, ext_comps, ext_gcomps, Vector{Float64}[])
     finalizer(e -> (@ccall lib.dto_destroy(e.handle::Ptr{Cvoid})::Cvoid), ev)
     return ev
 end
@@ -403,6 +459,14 @@ function stage_external!(ev::GPUEvaluator, Z::AbstractVector{Float64}; con_need:
     for (con, row) in ev.ext_constraints
         slot += 1
         con_need < 0 && continue
+        if con isa NonlinearGlobalConstraint   # one listing: values g, Jacobian g_dim x n_comps, Hessian of mu' g (global_constraint.jl:102-134)
+            gv = Vector{Float64}(traj.global_data[ev.ext_gcomps[con]])
+            jac_p = con_need >= 1 ? stage(vec(Matrix{Float64}(ForwardDiff.jacobian(con.g, gv)))) : Ptr{Float64}(C_NULL)
+            μc = con_need >= 2 ? Vector{Float64}(μ[row:row+con.dim-1]) : Float64[]
+            hess_p = con_need >= 2 ? stage(vec(Matrix{Float64}(ForwardDiff.hessian(x -> μc' * con.g(x), gv)))) : Ptr{Float64}(C_NULL)
+            vals[slot] = ExternalValues(stage(Vector{Float64}(con.g(gv))), jac_p, hess_p)
+            continue
+        end
         g = zeros(con.dim)
         evaluate!(g, con, traj)
         jac_p = Ptr{Float64}(C_NULL)
@@ -424,6 +488,19 @@ function stage_external!(ev::GPUEvaluator, Z::AbstractVector{Float64}; con_need:
     for o in ev.ext_objectives
         slot += 1
         obj_need < 0 && continue
+        if o isa GlobalObjective || o isa GlobalKnotPointObjective
+            # blocks over xg = [z_t[comps]; global_data[gcomps]] per listing, differentiated as the reference does
+            # (ForwardDiff on the closure, global_objectives.jl:76-79, :117, :258, :330)
+            gv = Vector{Float64}(traj.global_data[ev.ext_gcomps[o]])
+            listings = o isa GlobalObjective ? [(x -> o.Q * o.ℓ(x), gv)] :
+                [(let i = i; x -> o.Qs[i] * o.ℓ(x, o.params[i]) end, vcat(vcat([traj[t][n] for n in o.var_names]...), gv))
+                 for (i, t) in enumerate(o.times)]
+            v = Float64[f(x) for (f, x) in listings]
+            grad_p = obj_need >= 1 ? stage(vcat([ForwardDiff.gradient(f, x) for (f, x) in listings]...)) : Ptr{Float64}(C_NULL)
+            hess_p = obj_need >= 2 ? stage(vcat([vec(ForwardDiff.hessian(f, x)) for (f, x) in listings]...)) : Ptr{Float64}(C_NULL)
+            vals[slot] = ExternalValues(stage(v), grad_p, hess_p)
+            continue
+        end
         comps1 = ev.ext_comps[o]
         nc = length(comps1)
         nt = length(o.times)
@@ -517,6 +594,65 @@ function constraint_bounds(ev::GPUEvaluator)
     check(ev, @ccall lib.dto_constraint_bounds(ev.handle::Ptr{Cvoid}, lo::Ptr{Float64}, hi::Ptr{Float64})::Cint)
     return lo, hi
 end
+
+# ---- device-resident entry points (MadNLP GPU mode, src/solvers/madnlp_solver/options.jl:12-16) ---------------------------
+# Pointers are DEVICE pointers (e.g. `Ptr{Float64}(UInt(pointer(A)))` of an AMDGPU.ROCArray{Float64}), `stream` the HIP
+# stream of those arrays; outputs stay in HBM and the call returns with its last kernels in flight on `stream`.  Closure-based
+# terms are evaluated on the host: pass the host copy of Z (and of mu) as `Z_host` / `μ_host` for problems that have any.
+function eval_objective_dev!(ev::GPUEvaluator, df::Ptr{Float64}, dZ::Ptr{Float64}, stream::Ptr{Cvoid}; Z_host = nothing)
+    Z_host === nothing || stage_external!(ev, Z_host; obj_need = 0)
+    check(ev, @ccall lib.dto_eval_objective_dev(ev.handle::Ptr{Cvoid}, dZ::Ptr{Float64}, df::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+end
+function eval_objective_gradient_dev!(ev::GPUEvaluator, d∇::Ptr{Float64}, dZ::Ptr{Float64}, stream::Ptr{Cvoid}; Z_host = nothing)
+    Z_host === nothing || stage_external!(ev, Z_host; obj_need = 1)
+    check(ev, @ccall lib.dto_eval_gradient_dev(ev.handle::Ptr{Cvoid}, dZ::Ptr{Float64}, d∇::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+end
+function eval_constraint_dev!(ev::GPUEvaluator, dg::Ptr{Float64}, dZ::Ptr{Float64}, stream::Ptr{Cvoid}; Z_host = nothing)
+    Z_host === nothing || stage_external!(ev, Z_host; con_need = 0)
+    check(ev, @ccall lib.dto_eval_constraint_dev(ev.handle::Ptr{Cvoid}, dZ::Ptr{Float64}, dg::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+end
+function eval_constraint_jacobian_dev!(ev::GPUEvaluator, d∂::Ptr{Float64}, dZ::Ptr{Float64}, stream::Ptr{Cvoid}; Z_host = nothing)
+    Z_host === nothing || stage_external!(ev, Z_host; con_need = 1)
+    check(ev, @ccall lib.dto_eval_jacobian_dev(ev.handle::Ptr{Cvoid}, dZ::Ptr{Float64}, d∂::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+end
+function eval_hessian_lagrangian_dev!(ev::GPUEvaluator, dH::Ptr{Float64}, dZ::Ptr{Float64}, σ::Float64, dμ::Ptr{Float64}, stream::Ptr{Cvoid};
+                                      Z_host = nothing, μ_host = nothing)
+    Z_host === nothing || stage_external!(ev, Z_host; con_need = 2, obj_need = σ != 0 ? 2 : -1, μ = μ_host)
+    check(ev, @ccall lib.dto_eval_hessian_dev(ev.handle::Ptr{Cvoid}, dZ::Ptr{Float64}, σ::Float64, dμ::Ptr{Float64}, dH::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+end
+
+# ---- multi-GPU: one Julia process per GPU, `k_lo` / `k_hi` at construction; the engine owns the RCCL communicator --------------
+# (SURVEY.md section 8e; BASELINE configs[3]).  No callback needs a collective; these gather the per-rank value slabs for a
+# consumer that wants the whole vector on every GPU, and sum the objective's per-shard partial sums.
+"128 bytes from ncclGetUniqueId: call on ONE rank, hand them to the others (MPI.bcast, a file, a socket)."
+function comm_unique_id()
+    id = zeros(UInt8, DTO_COMM_ID_BYTES)
+    rc = @ccall lib.dto_comm_unique_id(id::Ptr{Cvoid})::Cint
+    rc == 0 || error(unsafe_string(@ccall lib.dto_last_error(C_NULL::Ptr{Cvoid})::Cstring))
+    return id
+end
+"Collective over the ranks: ncclCommInitRank on this handle's device + exchange of the ranks' knot ranges (rank is 0-based)."
+function comm_create!(ev::GPUEvaluator, id::Vector{UInt8}, rank::Integer, world::Integer)
+    r32, w32 = Int32(rank), Int32(world)
+    GC.@preserve id check(ev, @ccall lib.dto_comm_create(ev.handle::Ptr{Cvoid}, id::Ptr{Cvoid}, r32::Int32, w32::Int32)::Cint)
+end
+comm_destroy!(ev::GPUEvaluator) = check(ev, @ccall lib.dto_comm_destroy(ev.handle::Ptr{Cvoid})::Cint)
+"How to allocate one value vector (DTO_VECTOR_*) so that ONE in-place ncclAllGather moves every rank's slab: `padded_len` doubles; the vector starts at `front_pad`, this rank's slab at `front_pad + own_lo` (0-based offsets)."
+function gather_layout(ev::GPUEvaluator, vector::Int32)
+    L = Ref(GatherLayout(0, 0, 0, 0, 0, Int32(0), Int32(0)))
+    check(ev, @ccall lib.dto_get_gather_layout(ev.handle::Ptr{Cvoid}, vector::Int32, L::Ptr{GatherLayout})::Cint)
+    return L[]
+end
+gather_jacobian_dev!(ev::GPUEvaluator, dbuf::Ptr{Float64}, stream::Ptr{Cvoid}) =
+    check(ev, @ccall lib.dto_gather_jacobian_dev(ev.handle::Ptr{Cvoid}, dbuf::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+gather_hessian_dev!(ev::GPUEvaluator, dbuf::Ptr{Float64}, stream::Ptr{Cvoid}) =
+    check(ev, @ccall lib.dto_gather_hessian_dev(ev.handle::Ptr{Cvoid}, dbuf::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+gather_gradient_dev!(ev::GPUEvaluator, dbuf::Ptr{Float64}, stream::Ptr{Cvoid}) =
+    check(ev, @ccall lib.dto_gather_gradient_dev(ev.handle::Ptr{Cvoid}, dbuf::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+gather_constraint_dev!(ev::GPUEvaluator, dg_local::Ptr{Float64}, dg_full::Ptr{Float64}, stream::Ptr{Cvoid}) =
+    check(ev, @ccall lib.dto_gather_constraint_dev(ev.handle::Ptr{Cvoid}, dg_local::Ptr{Float64}, dg_full::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+allreduce_objective_dev!(ev::GPUEvaluator, df::Ptr{Float64}, stream::Ptr{Cvoid}) =
+    check(ev, @ccall lib.dto_allreduce_objective_dev(ev.handle::Ptr{Cvoid}, df::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
 
 function set_option!(ev::GPUEvaluator, name::AbstractString, value::Integer)
     v64 = Int64(value)

@@ -17,3 +17,13 @@ def pytest_configure(config):
 def engine_lib():
     import dto_amd
     return dto_amd.load_library()
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _host_xfer_self_check():
+    """Every handle the tests create checks its host-pointer Jacobian / Hessian against the whole device slab (option
+    host_xfer_check): a kernel that wrote outside the hand-off plan fails the call instead of being dropped silently."""
+    import dto_amd
+    dto_amd.Evaluator.default_options = {"host_xfer_check": 1}
+    yield
+    dto_amd.Evaluator.default_options = {}

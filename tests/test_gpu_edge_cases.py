@@ -2,6 +2,8 @@
 weights, sqnorm / equality constraints, duplicate constraint times), component orders that drop the
 (v,dt) Hessian cross terms, global variables, several bilinear integrators, zero-drive problems,
 minimum sizes, non-finite iterates."""
+import os
+
 import numpy as np
 import pytest
 
@@ -183,27 +185,51 @@ def test_chunked_propagator_chain():
     ev.close()
 
 
+_BAD_LAUNCH_CHILD = r"""
+import os, sys
+root = os.environ["DTO_ROOT"]
+for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import dto_amd, dto_oracle as O
+from helpers import to_engine, rel_err
+for general in (False, True):
+    p = O.make_scaled_problem(5, 9, 2, seed=8, with_constraint=True)
+    ev_o = O.OracleEvaluator(p)
+    ev = dto_amd.Evaluator(to_engine(p), general_path_only=general)
+    j = np.full(ev.shard.jac_len, np.nan)
+    ev.set_option("debug_bad_launch", 1)
+    for call in (lambda: ev.eval_constraint_jacobian(j, p.Z0), lambda: ev.eval_constraint(np.full(ev.shard.cons_len, np.nan), p.Z0)):
+        try:
+            call()
+            raise SystemExit("the rejected launch did not come back as an error")
+        except dto_amd.EngineError as e:
+            assert "launch" in str(e) or "invalid" in str(e), str(e)
+    ev.set_option("debug_bad_launch", 0)
+    ev.eval_constraint_jacobian(j, p.Z0)
+    assert rel_err(j, ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10
+    ev.close()
+print("child-ok")
+"""
+
+
 def test_rejected_kernel_launch_comes_back_as_an_error():
-    """include/dto_engine.h error convention: non-zero return + text.  Option debug_bad_launch gives the callbacks' kernels a
-    launch configuration the hardware does not have (block of 4096 threads on the general path, 512 KB of LDS more than a CU
-    owns on the fused small-state path); the call must fail through the ABI, and the handle must work again afterwards."""
+    """include/dto_engine.h error convention: non-zero return + text.  The TUNING build's option debug_bad_launch gives the
+    callbacks' kernels a launch configuration the hardware does not have (block of 4096 threads on the general path, 512 KB of
+    LDS more than a CU owns on the fused small-state path); the call must fail through the ABI, and the handle must work again
+    afterwards.  The product library does not know the option (it is a test hook): it refuses the name."""
+    import subprocess
+    import sys
     import dto_amd
-    EngineError = dto_amd.EngineError
-    for general in (False, True):
-        p = O.make_scaled_problem(5, 9, 2, seed=8, with_constraint=True)
-        ev_o = O.OracleEvaluator(p)
-        ev = dto_amd.Evaluator(to_engine(p), general_path_only=general)
-        j = np.full(ev.shard.jac_len, np.nan)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTO_ROOT=root, DTO_ENGINE_LIB="libdto_engine_t.so")
+    r = subprocess.run([sys.executable, "-c", _BAD_LAUNCH_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child-ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    p = O.make_scaled_problem(5, 9, 2, seed=8)
+    ev = dto_amd.Evaluator(to_engine(p))
+    with pytest.raises(dto_amd.EngineError, match="TUNING builds only"):
         ev.set_option("debug_bad_launch", 1)
-        with pytest.raises(EngineError, match="launch|invalid"):
-            ev.eval_constraint_jacobian(j, p.Z0)
-        g = np.full(ev.shard.cons_len, np.nan)
-        with pytest.raises(EngineError):
-            ev.eval_constraint(g, p.Z0)
-        ev.set_option("debug_bad_launch", 0)
-        ev.eval_constraint_jacobian(j, p.Z0)
-        assert rel_err(j, ev_o.eval_constraint_jacobian(p.Z0)) <= 1e-10
-        ev.close()
+    ev.close()
 
 
 def test_output_buffers_are_checked_on_the_host():

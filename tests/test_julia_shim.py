@@ -39,7 +39,7 @@ def jl_struct(name):
 def test_struct_layouts_match_the_header():
     for jl, c in (("IntegratorDesc", "dto_integrator_desc"), ("ObjectiveDesc", "dto_objective_desc"),
                   ("ConstraintDesc", "dto_constraint_desc"), ("ProblemDesc", "dto_problem_desc"),
-                  ("ExternalValues", "dto_external_values")):
+                  ("ExternalValues", "dto_external_values"), ("GatherLayout", "dto_gather_layout")):
         assert jl_struct(jl) == c_struct(c), (jl, jl_struct(jl), c_struct(c))
 
 
@@ -47,7 +47,10 @@ def test_constants_match_the_header():
     defs = dict(re.findall(r"#define (DTO_\w+) (\d+)", H))
     for name, val in re.findall(r"const (DTO_\w+) = Int32\((\d+)\)", JL):
         assert defs[name] == val, name
-    assert "DTO_ABI_VERSION" in dict(re.findall(r"const (DTO_\w+) = Int32\((\d+)\)", JL))
+    consts = dict(re.findall(r"const (DTO_\w+) = Int32\((\d+)\)", JL))
+    for need in ("DTO_ABI_VERSION", "DTO_OBJECTIVE_EXTERNAL_GLOBAL", "DTO_CONSTRAINT_EXTERNAL_GLOBAL", "DTO_VECTOR_JACOBIAN",
+                 "DTO_VECTOR_HESSIAN", "DTO_VECTOR_GRADIENT", "DTO_VECTOR_CONSTRAINT", "DTO_COMM_ID_BYTES"):
+        assert need in consts, need
 
 
 def _c_prototypes():
@@ -60,7 +63,14 @@ def _c_prototypes():
 def test_every_ccall_names_an_entry_point_with_the_right_argument_count():
     protos = _c_prototypes()
     calls = re.findall(r"@ccall\(?\s*lib\.(dto_\w+)\((.*?)\)::(\w+)", JL, flags=re.S)
-    assert len(calls) >= 15
+    assert len(calls) >= 30
+    called = {name for name, _, _ in calls}
+    # the device-resident callbacks (MadNLP GPU mode) and the engine's collectives are bound too
+    for need in ("dto_eval_objective_dev", "dto_eval_gradient_dev", "dto_eval_constraint_dev", "dto_eval_jacobian_dev",
+                 "dto_eval_hessian_dev", "dto_comm_unique_id", "dto_comm_create", "dto_comm_destroy", "dto_get_gather_layout",
+                 "dto_gather_jacobian_dev", "dto_gather_hessian_dev", "dto_gather_gradient_dev", "dto_gather_constraint_dev",
+                 "dto_allreduce_objective_dev"):
+        assert need in called, need
     for name, args, ret in calls:
         assert name in protos, name
         n_args = len([a for a in re.split(r",(?![^{]*\})", args) if a.strip()])
@@ -75,6 +85,10 @@ def test_every_moi_method_of_the_reference_evaluator_is_forwarded():
         assert re.search(r"MOI\.%s\(" % method, JL), method
     # generators come from the closure the integrator stores (it has no G field), external terms reach dto_set_external
     assert "B.f.G" in JL and "B.G(" not in JL and "dto_set_external" in JL and "finalizer" in JL
+    # the Global* kinds are merged, not refused (global_objectives.jl:35-350, global_constraint.jl:20-160)
+    for kind in ("GlobalObjective", "GlobalKnotPointObjective", "NonlinearGlobalConstraint"):
+        assert re.search(r"isa %s\b" % kind, JL), kind
+    assert "DTO_OBJECTIVE_EXTERNAL_GLOBAL," in JL and "DTO_CONSTRAINT_EXTERNAL_GLOBAL," in JL
     # no elided code: "..." only ever appears as Julia's splat operator, directly behind an expression
     for m in re.finditer(r"\.\.\.", JL):
         assert JL[m.start() - 1] in "])s", JL[max(0, m.start() - 40):m.end() + 5]
