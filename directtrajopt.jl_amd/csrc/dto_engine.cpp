@@ -81,6 +81,13 @@ struct BilHost {
     // eval_constraint and the Hessian's forward sweep store them), p_steps + 1 of them, valid counts per block in fw.nterms_p
     bool p_terms = false;
     int p_steps = 0;
+    int p_nblk = 0;           // intervals per entry of fw.nterms_p (the convergence blocks of the sweep that stored the p terms)
+    // row-split cluster sweeps (dto_sweep_fused.hip): exchange slabs and arrival counters, one set per sweep buffer (the
+    // Hessian's forward and adjoint sweeps may run side by side), grow-only
+    double* xch[2] = {nullptr, nullptr};
+    unsigned* xch_arrive[2] = {nullptr, nullptr};
+    size_t xch_cap[2] = {0, 0};
+    int xch_clusters[2] = {0, 0};
     bool small = false;       // n <= 32: fused one-workgroup-per-interval path (dto_small.hip)
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
@@ -558,6 +565,8 @@ int fused_sweep_steps(dto_handle* h, const SweepBuf& w, int d_ub, hipStream_t st
     return std::max(1, std::min(hs[1] - 1, d_ub));
 }
 bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store);
+bool cluster_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
+                           ClusterSweepPlan& cp);
 
 // Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
@@ -586,6 +595,34 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
             // flops of the step budget (an upper bound: workgroups leave when their columns have converged)
             ProfScope ps(h, st, prof_cat, flops_step * plan.d_ub * plan.q);
             HIP_CHECK(launch_sweep_fused(st, h->P, b.k, w, ty, fp, dZ, dmu, src_kind, transposed, plan.q, plan.d_ub, tc, store, 1.1e-16));
+        }
+        if (!want_steps) return plan.d_ub;
+        return fused_sweep_steps(h, w, plan.d_ub, st);
+    }
+    // Row-split cluster form: where the single-workgroup form has too few interval groups for the chip -- short shards of 128-
+    // and 256-state problems (the 250-knot share of the 2000-knot metric on 8 GPUs).  Measured per Jacobian / Hessian,
+    // cluster against step per launch (tools/cluster_time.py): 256 x 250 2.12 / 2.02 against 2.22 / 2.04 ms, 128 x 250 0.74 /
+    // 1.02 against 0.93 / 1.18 ms.  NOT used where it measured slower: single-column sweeps (eval_constraint 0.94 against
+    // 0.62 ms at 250 knots, 1.52 against 1.45 at 2000: the rendezvous + slice exchange costs ~10 us per Taylor step, as much
+    // as the step's MFMA work there) and 512 / 1024 states (23.6 against 18.7 ms, 57 against 47 ms per Jacobian: the step
+    // launches tile the 2500 columns 32 wide, a cluster member is held to 16 by its LDS).  Not with frozen p terms or the
+    // products' extra start vector.
+    ClusterSweepPlan cp;
+    if (!skip_init && cluster_sweep_applies(h, b, w, ty, plan, store, cp)) {
+        const int wi = &w == &b.ad ? 1 : 0;
+        const size_t need = sweep_cluster_workspace_doubles(w.npad, cp);
+        if (need > b.xch_cap[wi] || cp.n_clusters > b.xch_clusters[wi]) {
+            b.xch[wi] = own(h, dalloc<double>(need));
+            b.xch_arrive[wi] = own(h, dalloc<unsigned>((size_t)cp.n_clusters));
+            b.xch_cap[wi] = need;
+            b.xch_clusters[wi] = cp.n_clusters;
+        }
+        w.nblk = cp.ipw;
+        HIP_CHECK(hipMemsetAsync(w.stats, 0, 4 * sizeof(int32_t), st));
+        {
+            ProfScope ps(h, st, prof_cat, flops_step * plan.d_ub * plan.q);
+            HIP_CHECK(launch_sweep_cluster(st, h->P, b.k, w, ty, cp, b.xch[wi], b.xch_arrive[wi], dZ, dmu, src_kind, transposed, plan.q,
+                                           plan.d_ub, tc, store, 1.1e-16));
         }
         if (!want_steps) return plan.d_ub;
         return fused_sweep_steps(h, w, plan.d_ub, st);
@@ -881,6 +918,19 @@ bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& 
            sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp);
 }
 
+bool cluster_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
+                           ClusterSweepPlan& cp) {
+    static const int on = tune_int("DTO_SWEEP_CLUSTER", 1);  // A/B runs (TUNING builds): 0 = never
+    static const int big = tune_int("DTO_SWEEP_CLUSTER_BIG", 0);  // 512 and 1024 states as well
+    static const int t1 = tune_int("DTO_SWEEP_CLUSTER_T1", 0);    // single-column sweeps too
+    if (!on || h->sweep_form == 1 || w.frozen) return false;
+    if (ty.T == 1 && !t1) return false;
+    if (store && !(w.Zt && plan.d_ub + 1 <= w.dcap)) return false;
+    if (store && ty.T == 1 && h->reuse) return false;
+    if (w.npad > 256 && !big) return false;
+    return sweep_cluster_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, cp);
+}
+
 // max_k ||A_k^2||_1^(1/2), exact, for callbacks that do not run the propagator chain: A_k and A_k^2 only
 // (one streaming pass + one small GEMM per chunk).  Sharper than the generator-norm bound, so the sweep
 // usually needs a single round (q = 1).
@@ -1044,8 +1094,9 @@ void do_gradient(dto_handle* h, const double* dZ, double* dgrad, hipStream_t st)
 void remember_p_terms(dto_handle* h, BilHost& b, bool stored, int steps, hipStream_t st) {
     b.p_terms = stored && h->reuse;
     b.p_steps = steps;
+    b.p_nblk = b.fw.nblk;
     if (stored)
-        HIP_CHECK(hipMemcpyAsync(b.fw.nterms_p, b.fw.nterms, sizeof(int32_t) * (b.fw.Kpad / b.fw.TN), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(b.fw.nterms_p, b.fw.nterms, sizeof(int32_t) * b.fw.Kpad, hipMemcpyDeviceToDevice, st));
 }
 
 void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) {
@@ -1235,7 +1286,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 const int64_t typesz = (int64_t)b.fw.Kpad * b.k.npad;
                 const int64_t cols = (int64_t)na * b.fw.Kpad;  // one type of every stored term
                 SweepBuf plain = b.fw;
-                if (Tf == 1) { plain.nterms = b.fw.nterms_p; plain.nblk = b.fw.TN; }  // (a frozen Jacobian sweep in between re-used fw.nterms)
+                if (Tf == 1) { plain.nterms = b.fw.nterms_p; plain.nblk = b.p_nblk; }  // (a frozen Jacobian sweep in between re-used fw.nterms)
                 launch_pair_combine(st, plain, Tf, 1, na, nf, b.ad.nterms, b.ad.nblk, b.d_Btab, b.Upair);
                 {
                     ProfScope ps(h, st, CAT_SWEEP, 2.0 * b.k.npad * (double)b.k.npad * cols * m);
@@ -1658,6 +1709,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
             HIP_CHECK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
             HIP_CHECK(sweep_fused_prepare());
+            HIP_CHECK(sweep_cluster_prepare());
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;

@@ -243,6 +243,20 @@ hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, con
                               const FusedSweepPlan& pl, const double* dZ, const double* dmu, int src_kind, int transposed,
                               int q, int d_ub, int tc, bool store, double tol);
 
+// ---- the same sweep with the rows of the matrix split over a cluster of R workgroups that exchange their slices of every new
+// term through global memory (dto_sweep_fused.hip): short shards, single-column sweeps, 512+ states
+struct ClusterSweepPlan {
+    int MT, NT, R, ipw, n_groups, n_clusters, nblocks;
+    size_t lds_bytes;
+    double step_us;  // the cost model's time per Taylor step and round of clusters
+};
+hipError_t sweep_cluster_prepare();
+bool sweep_cluster_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, ClusterSweepPlan& out);
+size_t sweep_cluster_workspace_doubles(int npad, const ClusterSweepPlan& pl);
+hipError_t launch_sweep_cluster(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
+                                const ClusterSweepPlan& pl, double* X, unsigned* arrive, const double* dZ, const double* dmu,
+                                int src_kind, int transposed, int q, int d_ub, int tc, bool store, double tol);
+
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
                        int t, int in_buf, int split_store = 0);
 void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);

@@ -435,6 +435,484 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same sweep with the ROWS of the matrix split over a cluster of R workgroups (round 3).
+//
+// k_sweep_fused gives one workgroup all npad rows of a few intervals; it needs npad <= 256 and at least half a workgroup
+// per CU, i.e. >= 9 x 128 intervals for a Jacobian sweep at 256 states.  A 250-knot shard (strong scaling over 8 GPUs), a
+// single-column sweep (eval_constraint, the Hessian's forward sweep: 2000 columns = 125 column tiles) or 512+ states offer
+// their parallelism in the ROW dimension.  Here R workgroups (on R CUs) share an interval group: each holds ALL term columns
+// in LDS (the B operand of G_g * column needs the whole column) but computes only its npad / R rows of the next term, then
+// the R slices are exchanged through global memory:
+//
+//   publish   every lane stores its new-term elements into X[cluster][t & 1][column][row] with 8-byte AGENT-scope atomic
+//             stores (`global_store_dwordx2 sc1`: write-through, nothing left dirty in the XCD's L2), every wave drains
+//             (`s_waitcnt vmcnt(0)`), the workgroup's barrier, then ONE lane adds 1 to the cluster's arrival counter
+//   rendezvous one lane polls the counter (sc1 load + s_sleep) until all R workgroups of step t have arrived; barrier
+//   collect   every lane reads the OTHER workgroups' slices with 8-byte agent-scope atomic loads (sc1: never served from
+//             this CU's L1) straight into the LDS columns
+//
+// -- the "8-byte agent atomics on both sides" hand-off of MI355X_MICROARCH.md (Workgroup dispatch ... visibility, Valid forms
+// and its table, first row: one lane of each storing workgroup signals for all its stores behind the workgroup's barrier; an
+// sc1 poll of that counter; the other waves load behind a barrier the polling wave joins; hipMalloc memory; ONE workgroup per
+// CU -- the launch pads its LDS request beyond half a CU's to guarantee that).  X is double buffered by step parity: a
+// workgroup can only write step t+2 after every member has published t+1, i.e. has finished reading t.  Every spin is
+// bounded: a member that does not arrive within ~0.5 s makes the sweep report "not converged" instead of hanging.
+// Column norms are exchanged the same way (each workgroup knows only its rows' maxima), so all R members take the SAME
+// termination decision from the same numbers.  Results are a function of (plan, data) alone: fixed K order per cluster.
+struct ClusterArgs {
+    FusedSweepArgs f;
+    double* X;            // [clusters][2][NC_pad * npad + 8 * NC_pad] exchange slabs (terms, then norms)
+    unsigned* arrive;     // [clusters] monotonic arrival counters (zeroed by the launcher)
+    int n_groups;         // interval groups of ipw intervals
+    int n_clusters;       // clusters in the grid (each walks groups cluster, cluster + n_clusters, ...)
+};
+
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int MT, int NT, int R>
+__global__ void __launch_bounds__(256, 1) k_sweep_cluster(ClusterArgs ca) {
+    const FusedSweepArgs& a = ca.f;
+    constexpr int NTHREADS = 256, NWAVES = 4;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int RL = 16 * MT;          // rows per wavefront
+    constexpr int RW = 4 * RL;           // rows per workgroup = npad / R
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int npad = a.w.npad, Kpad = a.w.Kpad, T = a.ty.T, m = a.B.m, ipw = a.ipw;
+    const int NC = T * ipw, ZS = npad + 2, KS = npad / 4;
+    const int64_t typesz = (int64_t)Kpad * npad, nn = (int64_t)npad * npad;
+    // cluster members sit on one XCD under the observed round-robin placement (blocks b and b + 8 share one): speed only
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int rank = jb % R, cluster = (jb / R) * 8 + xcd;
+    if (cluster >= ca.n_clusters) return;
+    const FusedLds L(npad, T, m, ipw, a.nslot, MT);
+    double* Zs = lds + L.zs;
+    double* cg = lds + L.cg;
+    double* sE = lds + L.se;
+    unsigned long long* tn = reinterpret_cast<unsigned long long*>(lds + L.tn);
+    unsigned long long* sn = reinterpret_cast<unsigned long long*>(lds + L.sn);
+    double* xm = lds + L.xm;
+    int* xn = reinterpret_cast<int*>(lds + L.xn);
+    int* xg = reinterpret_cast<int*>(lds + L.xg);
+    int* xs = reinterpret_cast<int*>(lds + L.xs);
+    int* flag = reinterpret_cast<int*>(lds + L.flag);
+    const int NCP = 16 * NT;                                   // padded column count
+    const int64_t xslab = (int64_t)NCP * npad + 8 * NCP;       // doubles per (cluster, parity): term slices, then [2 R][NCP] norms
+    double* Xc = ca.X + (int64_t)cluster * 2 * xslab;
+    unsigned* arrive = ca.arrive + cluster;
+    unsigned arrivals = 0;                                      // rendezvous passed so far (x R = counter value to wait for)
+    bool dead = false;                                          // a rendezvous timed out: finish without converging
+
+    if (tid < T) {
+        const TypeDesc td = a.ty.t[tid];
+        xn[tid] = td.n_extra;
+        xg[2 * tid] = td.gen[0]; xg[2 * tid + 1] = td.gen[1];
+        xs[2 * tid] = td.src[0]; xs[2 * tid + 1] = td.src[1];
+        xm[2 * tid] = td.mult[0]; xm[2 * tid + 1] = td.mult[1];
+    }
+    const int rowbase = rank * RW + (wave & 3) * RL;
+    auto lane_row = [&](int ti) { return MT >= 2 ? rowbase + 32 * (ti / 2) + 2 * lr + (ti & 1) : rowbase + lr; };
+    const int64_t astep = 4 * (int64_t)npad;
+    const double* const aend = a.G + (int64_t)(m + 1) * nn;
+    int t_max = 0, n_bad = 0;
+
+    for (int grp = cluster; grp < ca.n_groups; grp += ca.n_clusters) {
+        const int k0 = grp * ipw;
+        __syncthreads();  // the previous group's LDS is done with
+        // ---- per-interval coefficients, term 0 (every member loads the whole columns itself)
+        if (tid < ipw) {
+            const int kl = k0 + tid;
+            const bool live = kl < a.P.n_int;
+            const double* zk = a.Zsrc + (a.P.kn_lo + kl) * a.P.z;
+            const double dt = live ? zk[a.P.dt_idx] : 0.0;
+            const double inv_q = 1.0 / a.q;
+            sE[tid] = dt * inv_q;
+            if (rank == 0 && kl < Kpad) {
+                a.w.scaleE[kl] = dt * inv_q;
+                a.w.scaleE[Kpad + kl] = 2.0 * dt * inv_q;
+            }
+            for (int g = 0; g <= m; ++g) {
+                const double ub = live ? (g == 0 ? 1.0 : zk[a.B.u_off + g - 1]) : 0.0;
+                cg[g * ipw + tid] = dt * ub * inv_q;
+                if (rank == 0 && kl < Kpad) {
+                    a.w.scaleU[(int64_t)g * Kpad + kl] = ub;
+                    a.w.scaleA[(int64_t)g * Kpad + kl] = dt * ub * inv_q;
+                }
+            }
+        }
+        if (tid < 2) flag[tid] = 0;
+        for (int c = tid; c < 3 * NC; c += NTHREADS) tn[c] = 0ull;
+        for (int c = tid; c < NC; c += NTHREADS) sn[c] = 0ull;
+        __syncthreads();
+        {
+            double* Z0 = a.store ? a.w.Zt : a.w.Z[0];
+            const bool to_global = a.store != 0 && rank == 0;
+            for (int c = wave; c < NC; c += NWAVES) {
+                const int ty = c / ipw, i = c - ty * ipw, kl = k0 + i;
+                const bool live = ty == 0 && kl < a.P.n_int;
+                const int64_t kn = a.P.kn_lo + kl;
+                double mx = 0.0;
+                for (int r = lane; r < npad; r += 64) {
+                    double v = 0.0;
+                    if (live && r < a.B.n) v = a.src_kind == 0 ? a.Zsrc[kn * a.P.z + a.B.x_off + r] : a.mu[a.B.row_off + kn * a.B.n + r];
+                    Zs[c * ZS + r] = v;
+                    if (to_global && kl < Kpad) Z0[((int64_t)ty * Kpad + kl) * npad + r] = v;
+                    mx = fmax(mx, fabs(v));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+                if (lane == 0) { tn[c] = fbits(mx); sn[c] = fbits(mx); }
+            }
+        }
+        __syncthreads();
+
+        int bcol[NT], bty[NT], bin[NT];
+        bool bok[NT];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            const int c = 16 * tj + lr;
+            bok[tj] = c < NC;
+            const int cc = bok[tj] ? c : NC - 1;
+            bty[tj] = cc / ipw;
+            bin[tj] = cc - bty[tj] * ipw;
+            bcol[tj] = cc * ZS + lq;
+        }
+        const int g_first = grp % (m + 1);
+        const int ks_first = ((grp / (m + 1)) & 3) * (KS / 4);
+        d4 sreg[MT][NT];
+#pragma unroll
+        for (int ti = 0; ti < MT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * tj + 4 * r + lq;
+                    sreg[ti][tj][r] = c < NC ? Zs[c * ZS + lane_row(ti)] : 0.0;
+                }
+
+        int t_exit = 0;
+        bool conv = false;
+        for (int round = 0; round < a.q; ++round) {
+            if (round > 0) {
+                // next sub-interval of exp(A) = exp(A/q)^q: the sums become term 0 of the new series -- every member needs all
+                // rows of them, so they go through the exchange like a term
+                __syncthreads();
+                double* Xs = Xc + (int64_t)(arrivals & 1) * xslab;
+#pragma unroll
+                for (int ti = 0; ti < MT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * tj + 4 * r + lq;
+                            if (c < NC) {
+                                Zs[c * ZS + lane_row(ti)] = sreg[ti][tj][r];
+                                st_agent(&Xs[(int64_t)c * npad + lane_row(ti)], sreg[ti][tj][r]);
+                            }
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                ++arrivals;
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    long spins = 0;
+                    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals * R) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1L << 19)) { flag[0] = 2; break; }
+                    }
+                }
+                __syncthreads();
+                if (flag[0] == 2) dead = true;
+                for (int e = tid; e < NC * (npad - RW); e += NTHREADS) {
+                    const int c = e / (npad - RW);
+                    int r = e - c * (npad - RW);
+                    if (r >= rank * RW) r += RW;  // skip the own slice
+                    Zs[c * ZS + r] = ld_agent(&Xs[(int64_t)c * npad + r]);
+                }
+                __syncthreads();
+                for (int c = wave; c < NC; c += NWAVES) {
+                    double mx = 0.0;
+                    for (int r = lane; r < npad; r += 64) mx = fmax(mx, fabs(Zs[c * ZS + r]));
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+                    if (lane == 0) { tn[c] = fbits(mx); tn[NC + c] = 0ull; tn[2 * NC + c] = 0ull; sn[c] = fbits(mx); }
+                }
+                if (tid < 2) flag[tid] = 0;
+                __syncthreads();
+            }
+            conv = false;
+            int t = 0;
+            for (; t < a.d_ub && !dead; ++t) {
+                double* Zout = a.store ? a.w.Zt + (int64_t)(t + 1) * T * typesz : a.w.Z[(t + 1) & 1];
+                unsigned long long* tn_new = tn + ((t + 1) % 3) * NC;
+                const double inv = 1.0 / (double)(t + 1);
+                d4 acc[MT][NT];
+                double* Xs = Xc + (int64_t)(arrivals & 1) * xslab;
+                double* Xn = Xs + (int64_t)NCP * npad;  // norms: [rank][2][NCP] would need R slots; use [2 R][NCP] below
+                {
+                    const int aoff = lq * npad + rowbase + (MT >= 2 ? 2 * lr : lr);
+#pragma unroll
+                    for (int ti = 0; ti < MT; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = d4{0.0, 0.0, 0.0, 0.0};
+                    constexpr int AP = MT >= 2 ? MT / 2 : 1;
+                    d2 abuf[PF][AP];
+                    const double* abase = a.G + ((int64_t)g_first * KS + ks_first) * astep;
+                    auto issue = [&](int slot) {
+                        const double* p = abase + aoff;
+#pragma unroll
+                        for (int q2 = 0; q2 < AP; ++q2) {
+                            if constexpr (MT >= 2) abuf[slot][q2] = *reinterpret_cast<const d2*>(p + 32 * q2);
+                            else abuf[slot][q2] = d2{p[0], 0.0};
+                        }
+                        abase += astep;
+                        if (abase == aend) abase = a.G;
+                    };
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) issue(u);
+                    const int nseg = ks_first ? m + 2 : m + 1;
+                    for (int seg = 0; seg < nseg; ++seg) {
+                        int g = g_first + seg;
+                        if (g > m) g -= m + 1;
+                        if (seg == m + 1) g = g_first;
+                        const int ks_lo = seg == 0 ? ks_first : 0, ks_hi = seg == m + 1 ? ks_first : KS;
+                        double cA[NT], cB[NT];
+                        const double* zp1[NT];
+                        const double* zp2[NT];
+                        double z1[NT], z2[NT];
+#pragma unroll
+                        for (int tj = 0; tj < NT; ++tj) {
+                            cA[tj] = bok[tj] ? cg[g * ipw + bin[tj]] : 0.0;
+                            cB[tj] = 0.0;
+                            int so = bcol[tj];
+                            const int ne = bok[tj] ? xn[bty[tj]] : 0;
+                            for (int x = 0; x < ne; ++x)
+                                if (xg[2 * bty[tj] + x] == g) {
+                                    cB[tj] = sE[bin[tj]] * xm[2 * bty[tj] + x];
+                                    so = (xs[2 * bty[tj] + x] * ipw + bin[tj]) * ZS + lq;
+                                }
+                            zp1[tj] = Zs + bcol[tj] + 4 * ks_lo;
+                            zp2[tj] = Zs + so + 4 * ks_lo;
+                            z1[tj] = zp1[tj][0];
+                            z2[tj] = zp2[tj][0];
+                        }
+                        for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += PF) {
+#pragma unroll
+                            for (int u = 0; u < PF; ++u) {
+                                double bf[NT];
+#pragma unroll
+                                for (int tj = 0; tj < NT; ++tj) bf[tj] = cA[tj] * z1[tj] + cB[tj] * z2[tj];
+#pragma unroll
+                                for (int tj = 0; tj < NT; ++tj) {
+                                    z1[tj] = zp1[tj][4 * (u + 1)];
+                                    z2[tj] = zp2[tj][4 * (u + 1)];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int ti = 0; ti < MT; ++ti)
+#pragma unroll
+                                    for (int tj = 0; tj < NT; ++tj) {
+                                        double afv;
+                                        if constexpr (MT >= 2) afv = (ti & 1) ? abuf[u][ti / 2].y : abuf[u][ti / 2].x;
+                                        else afv = abuf[u][0].x;
+                                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[tj], afv, acc[ti][tj], 0, 0, 0);
+                                    }
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue(u);
+                            }
+#pragma unroll
+                            for (int tj = 0; tj < NT; ++tj) { zp1[tj] += 4 * PF; zp2[tj] += 4 * PF; }
+                        }
+                    }
+                    // ---- new term, own rows: sums, partial column norms, the store-mode copy, and the published slice
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * tj + 4 * r + lq;
+                            const int cc = c < NC ? c : 0;
+                            const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
+                            const bool ok = c < NC && kl < Kpad;
+                            const int64_t colbase = ((int64_t)ty * Kpad + kl) * npad + rowbase;
+                            double tmax = 0.0, smax = 0.0;
+                            bool bad_t = false, bad_s = false;
+                            if (c < NC) {
+#pragma unroll
+                                for (int p = 0; p < (MT >= 2 ? MT / 2 : 1); ++p) {
+                                    const int ro = MT >= 2 ? 32 * p + 2 * lr : lr;
+                                    d2 v, sv;
+                                    if constexpr (MT >= 2) v = d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
+                                    else v = d2{acc[0][tj][r] * inv, 0.0};
+                                    if constexpr (MT >= 2) {
+                                        sv = d2{sreg[2 * p][tj][r] + v.x, sreg[2 * p + 1][tj][r] + v.y};
+                                        sreg[2 * p][tj][r] = sv.x; sreg[2 * p + 1][tj][r] = sv.y;
+                                    } else {
+                                        sv = d2{sreg[0][tj][r] + v.x, 0.0};
+                                        sreg[0][tj][r] = sv.x;
+                                    }
+                                    if (a.store && ok) {
+                                        if constexpr (MT >= 2) *reinterpret_cast<d2*>(Zout + colbase + ro) = v;
+                                        else Zout[colbase + ro] = v.x;
+                                    }
+                                    st_agent(&Xs[(int64_t)c * npad + rowbase + ro], v.x);
+                                    if constexpr (MT >= 2) st_agent(&Xs[(int64_t)c * npad + rowbase + ro + 1], v.y);
+                                    tmax = fmax(tmax, fmax(fabs(v.x), fabs(v.y)));
+                                    smax = fmax(smax, fmax(fabs(sv.x), fabs(sv.y)));
+                                    bad_t = bad_t || !(v.x == v.x) || !(v.y == v.y);
+                                    bad_s = bad_s || !(sv.x == sv.x) || !(sv.y == sv.y);
+                                }
+                            }
+                            unsigned long long tb = bad_t ? 0x7ff8000000000000ull : fbits(tmax), sb = bad_s ? 0x7ff8000000000000ull : fbits(smax);
+#pragma unroll
+                            for (int o = 8; o > 0; o >>= 1) {
+                                const unsigned long long t2 = __shfl_xor(tb, o, 64), s2 = __shfl_xor(sb, o, 64);
+                                tb = t2 > tb ? t2 : tb;
+                                sb = s2 > sb ? s2 : sb;
+                            }
+                            if (c < NC && lr == 0) {
+                                atomicMax(&tn_new[c], tb);
+                                atomicMax(&sn[c], sb);
+                            }
+                        }
+                }
+                __syncthreads();  // every wave is done with the old term columns; this member's partial norms are complete
+                // own slice into the LDS columns; partial norms into the exchange slab
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * tj + 4 * r + lq;
+                        if (c < NC) {
+                            if constexpr (MT >= 2) {
+#pragma unroll
+                                for (int p = 0; p < MT / 2; ++p)
+                                    *reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * p + 2 * lr) =
+                                        d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
+                            } else {
+                                Zs[c * ZS + rowbase + lr] = acc[0][tj][r] * inv;
+                            }
+                        }
+                    }
+                if (tid < NC) {
+                    st_agent(&Xn[(int64_t)(2 * rank) * NCP + tid], fbits_to_d(tn_new[tid]));
+                    st_agent(&Xn[(int64_t)(2 * rank + 1) * NCP + tid], fbits_to_d(sn[tid]));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the barrier
+                __syncthreads();
+                ++arrivals;
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    long spins = 0;
+                    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals * R) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1L << 19)) { flag[t & 1] = 2; break; }   // bounded: a member that never arrives
+                    }
+                }
+                __syncthreads();
+                if (flag[t & 1] == 2) { dead = true; break; }
+                // the other members' slices and norms: ALL loads of a lane are issued before the first of them is used (an
+                // agent-scope load is a round trip to the fabric, ~1-2 us: one trip per lane, not one per element)
+                {
+                    constexpr int NOTHER = NT * 16 * (R - 1) * RW;        // upper bound on the slice elements to collect
+                    constexpr int PER = (NOTHER + NTHREADS - 1) / NTHREADS;
+                    constexpr int CH = PER < 8 ? PER : 8;                  // loads in flight per lane and trip
+                    const int total_e = NC * (npad - RW);
+                    unsigned long long tb = 0, sb = 0;
+                    double nrm[2 * (R - 1)];
+                    if (tid < NC) {
+                        int k = 0;
+#pragma unroll
+                        for (int o = 0; o < R; ++o) {
+                            if (o == rank) continue;
+                            nrm[k++] = ld_agent(&Xn[(int64_t)(2 * o) * NCP + tid]);
+                            nrm[k++] = ld_agent(&Xn[(int64_t)(2 * o + 1) * NCP + tid]);
+                        }
+                        tb = tn_new[tid]; sb = sn[tid];
+                    }
+                    for (int u0 = 0; u0 < PER; u0 += CH) {
+                        double got[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int e = tid + (u0 + u) * NTHREADS;
+                            if (e < total_e) {
+                                const int c = e / (npad - RW);
+                                int r = e - c * (npad - RW);
+                                if (r >= rank * RW) r += RW;
+                                got[u] = ld_agent(&Xs[(int64_t)c * npad + r]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int e = tid + (u0 + u) * NTHREADS;
+                            if (e < total_e) {
+                                const int c = e / (npad - RW);
+                                int r = e - c * (npad - RW);
+                                if (r >= rank * RW) r += RW;
+                                Zs[c * ZS + r] = got[u];
+                            }
+                        }
+                    }
+                    if (tid < NC) {
+#pragma unroll
+                        for (int k = 0; k < R - 1; ++k) {
+                            const unsigned long long t2 = (unsigned long long)__double_as_longlong(nrm[2 * k]);
+                            const unsigned long long s2 = (unsigned long long)__double_as_longlong(nrm[2 * k + 1]);
+                            tb = t2 > tb ? t2 : tb;
+                            sb = s2 > sb ? s2 : sb;
+                        }
+                        tn_new[tid] = tb;
+                        sn[tid] = sb;
+                    }
+                }
+                __syncthreads();
+                // Al-Mohy & Higham's test on the cluster-wide norms: the same decision in every member
+                if (t >= a.tc) {
+                    for (int c = tid; c < NC; c += NTHREADS) {
+                        const double a0 = fbits_to_d(tn[(t % 3) * NC + c]), a1 = fbits_to_d(tn_new[c]), s = fbits_to_d(sn[c]);
+                        if (!(a0 + a1 <= a.tol * s) && (a0 + a1 == a0 + a1) && s < 1e300) flag[t & 1] = 1;
+                    }
+                } else if (tid == 0) {
+                    flag[t & 1] = 1;
+                }
+                for (int c = tid; c < NC; c += NTHREADS) tn[((t + 2) % 3) * NC + c] = 0ull;
+                if (tid == 0) flag[(t + 1) & 1] = 0;
+                __syncthreads();
+                if (flag[t & 1] == 0) { conv = true; break; }
+            }
+            t_exit = conv ? t + 2 : a.d_ub + 1;
+        }
+        // the sums of this member's rows leave the registers once
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * tj + 4 * r + lq;
+                const int cc = c < NC ? c : 0;
+                const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
+                if (c < NC && kl < Kpad) {
+                    const int64_t colbase = ((int64_t)ty * Kpad + kl) * npad + rowbase;
+                    if constexpr (MT >= 2) {
+#pragma unroll
+                        for (int p = 0; p < MT / 2; ++p)
+                            *reinterpret_cast<d2*>(a.w.S + colbase + 32 * p + 2 * lr) = d2{sreg[2 * p][tj][r], sreg[2 * p + 1][tj][r]};
+                    } else {
+                        a.w.S[colbase + lr] = sreg[0][tj][r];
+                    }
+                }
+            }
+        if (tid == 0 && rank == 0) {
+            if (a.w.nterms) a.w.nterms[grp] = conv ? t_exit : 0;
+            t_max = t_exit > t_max ? t_exit : t_max;
+            if (!conv) ++n_bad;
+        }
+    }
+    if (tid == 0 && rank == 0) {
+        atomicMax(&a.w.stats[1], t_max);
+        if (n_bad) atomicAdd(&a.w.stats[0], n_bad);
+    }
+}
+
 template <int MT, int NT, int WC = 1>
 hipError_t launch_one(hipStream_t st, const FusedSweepArgs& a, int nblocks, size_t lds) {
     if (a.w.npad != 64 * MT) return hipErrorInvalidValue;
@@ -521,6 +999,116 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
     // used by another stream (`shared_chip`: the Jacobian's sweep next to the propagator chain), not when the sweep runs alone.
     if (shared_chip && npad == 256 && search(2)) return true;
     return search(1);
+}
+
+// ---- row-split cluster form: plan, workspace, launch
+namespace {
+template <int MT, int NT, int R>
+hipError_t launch_cluster_one(hipStream_t st, const ClusterArgs& a, int nblocks, size_t lds) {
+    if (a.f.w.npad != 64 * MT * R) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_sweep_cluster<MT, NT, R>), dim3(nblocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+template <int MT, int NT, int R>
+hipError_t prepare_cluster_one(int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_cluster<MT, NT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+}  // namespace
+
+hipError_t sweep_cluster_prepare() {
+    const int bytes = 160 * 1024;
+    hipError_t e = hipSuccess;
+#define DTO_PREPC(MT, NT, R) if (e == hipSuccess) e = prepare_cluster_one<MT, NT, R>(bytes)
+    DTO_PREPC(1, 1, 2); DTO_PREPC(1, 2, 2); DTO_PREPC(1, 3, 2);   // 128 states
+    DTO_PREPC(2, 1, 2); DTO_PREPC(2, 2, 2); DTO_PREPC(2, 3, 2);   // 256 states over 2
+    DTO_PREPC(1, 1, 4); DTO_PREPC(1, 2, 4); DTO_PREPC(1, 3, 4);   // 256 states over 4
+    DTO_PREPC(4, 1, 2); DTO_PREPC(4, 2, 2);                       // 512 states over 2
+    DTO_PREPC(2, 1, 4); DTO_PREPC(2, 2, 4);                       // 512 states over 4
+    DTO_PREPC(4, 1, 4);                                           // 1024 states over 4
+#undef DTO_PREPC
+    return e;
+}
+
+// Shape of the cluster launch: R members per interval group, NT column tiles (ipw = 16 NT / T intervals per group), as many
+// clusters as the chip holds with ONE workgroup per CU (a multiple of 8, one per XCD and slot); each cluster walks the groups
+// cluster, cluster + n_clusters, ...  Cost model per Taylor step, in MFMA units of one 16-column tile over 64 MT rows: the
+// tile count times the same L2 factor as the single-workgroup form (a narrow tile streams the generators faster than a CU
+// takes them in) plus the exchange (rendezvous + slice traffic), which does not shrink with the tile.
+bool sweep_cluster_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, ClusterSweepPlan& out) {
+    const int T = ty.T;
+    if (T < 1 || n_int <= 0 || n_cu < 16) return false;
+    static const double l2_factor[4] = {0.0, 1.6, 1.15, 1.0};
+    static const int force_r = tune_int("DTO_CLUSTER_R", 0), force_nt = tune_int("DTO_CLUSTER_NT", 0);
+    bool found = false;
+    double best = 0.0;
+    for (int R = 2; R <= 4; R += 2) {
+        if (npad % (64 * R) != 0) continue;
+        const int MT = npad / (64 * R);
+        if (MT != 1 && MT != 2 && MT != 4) continue;
+        if (force_r && R != force_r) continue;
+        for (int NT = 1; NT <= 3; ++NT) {
+            if (force_nt && NT != force_nt) continue;
+            const int ipw = (16 * NT) / T;
+            if (ipw < 1) continue;
+            if (NT > 1 && (16 * (NT - 1)) / T == ipw) continue;  // the narrower shape holds as many intervals
+            if (NT == 3 || (MT == 4 && NT > 1)) continue;  // three-tile shapes and 256 rows x 2 tiles spill beside the exchange registers
+            const FusedLds L(npad, T, m, ipw, 0, MT);
+            size_t bytes = (size_t)L.total * sizeof(double);
+            if (bytes > 156 * 1024) continue;
+            if (bytes < 82 * 1024) bytes = 82 * 1024;   // more than half a CU's LDS: one workgroup per CU (the hand-off's condition)
+            const long n_groups = (long)((n_int + ipw - 1) / ipw);
+            long n_clusters = ((long)(n_cu / R) / 8) * 8;
+            if (n_clusters > ((n_groups + 7) / 8) * 8) n_clusters = ((n_groups + 7) / 8) * 8;
+            if (n_clusters < 8) continue;
+            const long rounds = (n_groups + n_clusters - 1) / n_clusters;
+            const double step_us = MT * NT * l2_factor[NT] * (m + 1) * npad * 7.3e-3;   // 64 cycles per MFMA at 2.2 GHz
+            const double exch_us = 3.0 + 16.0 * NT * npad * 8.0 * 1e-3 / 60.0;           // rendezvous + slices at ~60 GB/s per CU
+            const double cost = rounds * (step_us + exch_us);
+            if (!found || cost < best) {
+                found = true; best = cost;
+                out.MT = MT; out.NT = NT; out.R = R; out.ipw = ipw; out.n_groups = (int)n_groups; out.n_clusters = (int)n_clusters;
+                out.nblocks = (int)(n_clusters * R); out.lds_bytes = bytes; out.step_us = step_us + exch_us;
+            }
+        }
+    }
+    return found;
+}
+
+size_t sweep_cluster_workspace_doubles(int npad, const ClusterSweepPlan& pl) {
+    const size_t NCP = 16 * (size_t)pl.NT;
+    return (size_t)pl.n_clusters * 2 * (NCP * npad + 8 * NCP);
+}
+
+hipError_t launch_sweep_cluster(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
+                                const ClusterSweepPlan& pl, double* X, unsigned* arrive, const double* dZ, const double* dmu,
+                                int src_kind, int transposed, int q, int d_ub, int tc, bool store, double tol) {
+    ClusterArgs c{};
+    FusedSweepArgs& a = c.f;
+    a.P = P; a.B = B; a.w = w; a.ty = ty;
+    a.G = transposed ? B.GT : B.G;
+    a.Zsrc = dZ; a.mu = dmu; a.src_kind = src_kind;
+    a.q = q; a.d_ub = d_ub; a.tc = tc; a.ipw = pl.ipw; a.store = store ? 1 : 0; a.nslot = 0; a.tol = tol;
+    c.X = X; c.arrive = arrive; c.n_groups = pl.n_groups; c.n_clusters = pl.n_clusters;
+    hipError_t e = hipMemsetAsync(arrive, 0, sizeof(unsigned) * (size_t)pl.n_clusters, st);
+    if (e != hipSuccess) return e;
+    const int key = pl.MT * 100 + pl.NT * 10 + pl.R;
+    switch (key) {
+        case 112: return launch_cluster_one<1, 1, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 122: return launch_cluster_one<1, 2, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 132: return launch_cluster_one<1, 3, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 212: return launch_cluster_one<2, 1, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 222: return launch_cluster_one<2, 2, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 232: return launch_cluster_one<2, 3, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 114: return launch_cluster_one<1, 1, 4>(st, c, pl.nblocks, pl.lds_bytes);
+        case 124: return launch_cluster_one<1, 2, 4>(st, c, pl.nblocks, pl.lds_bytes);
+        case 134: return launch_cluster_one<1, 3, 4>(st, c, pl.nblocks, pl.lds_bytes);
+        case 412: return launch_cluster_one<4, 1, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 422: return launch_cluster_one<4, 2, 2>(st, c, pl.nblocks, pl.lds_bytes);
+        case 214: return launch_cluster_one<2, 1, 4>(st, c, pl.nblocks, pl.lds_bytes);
+        case 224: return launch_cluster_one<2, 2, 4>(st, c, pl.nblocks, pl.lds_bytes);
+        case 414: return launch_cluster_one<4, 1, 4>(st, c, pl.nblocks, pl.lds_bytes);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
