@@ -519,12 +519,13 @@ def main():
             torch.cuda.synchronize(dev)
             step_ms.append((time.perf_counter() - t0) * 1e3)
 
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_call = None, None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
         import glob
         tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_traffic*.json")))[-1]))  # the latest round's
         if (n, Nk, args.callback) == (256, 2000, "jacobian"):
             traffic, traffic_src = tj["avg_per_launch_bytes"], tj["source"]
+            traffic_call = tj.get("per_call_total_bytes")
             pl = tj["per_launch_bytes"]
             prods = [v["read"] + v["write"] for k, v in pl.items() if k.startswith("product")]
             if "horner" in variants and prods:
@@ -563,6 +564,8 @@ def main():
                                             if args.callback == "hessian" else "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                # HBM-side bytes of ALL kernels of one call from the same PMC passes, against SURVEY.md §8d's algorithmic bytes
+                "traffic_per_call": traffic_call,
                 "launches": n_gemm, "avg_launch_ms": ms_gemm / max(n_gemm, 1),
                 "flops_per_launch": fl_gemm / max(n_gemm, 1),
                 "share_of_step": ms_gemm / ((overlapped["ms_per_step_serial_pass"] if overlapped else ms_per_step) * args.steps)

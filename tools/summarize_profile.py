@@ -9,13 +9,14 @@ import sys
 def main():
     tag, stats = sys.argv[1], sys.argv[2]
     out = [f"# rocprofv3 summary {tag}", "", "command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-callbacks --serial-kernels`",
-           "(7 eval_constraint_jacobian calls, 256-state x 2000-knot bilinear, 1x MI355X; --serial-kernels = option overlap_sweep 0, one kernel at a time)", "",
+           "(2 warm-up + 5 timed + 5 individually timed eval_constraint_jacobian calls, 256-state x 2000-knot bilinear, 1x MI355X; --serial-kernels = "
+           "option overlap_sweep 0, one kernel at a time; the 64x64 k_bgemm / k_add launches are create-time work)", "",
            "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for r in list(csv.DictReader(open(stats)))[:16]:
         out.append("| `%s` | %s | %.3f | %.1f | %s |" % (r["Name"][:80].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                        float(r["AverageNs"]) / 1e3, r["Percentage"]))
     if len(sys.argv) >= 5:
-        out += ["", "## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, 3 calls each)", "",
+        out += ["", "## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, 5 calls each)", "",
                 "FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for 16-B-per-lane streaming reads "
                 "(the counter tallies 128-B requests at 64 B); WRITE_SIZE is taken as read.", "",
                 "| kernel | launches | raw FETCH_SIZE MB | corrected read MB | WRITE_SIZE MB |", "|---|---|---|---|---|"]
