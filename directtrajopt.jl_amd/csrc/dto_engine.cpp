@@ -2168,7 +2168,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             t.d_vals = own(h, dalloc<double>(K * n));
             t.d_jac = own(h, dalloc<double>(K * n * 2 * z));
             if (d->eval_hessian) t.d_hess = own(h, dalloc<double>(K * 4 * z * z));
-            t.stride = (tdb_scratch_doubles(t.k, d->eval_hessian ? 2 : 1) + 1) & ~(size_t)1;
+            t.stride = (std::max(tdb_scratch_doubles(t.k, 1), d->eval_hessian ? tdb_scratch_doubles(t.k, 2) : (size_t)0) + 1) & ~(size_t)1;
             t.d_scratch = own(h, dalloc<double>(t.stride * (size_t)(P.n_knots + 1)));
         }
         // per-bilinear workspaces + generator product norms (for the step-budget bounds)

@@ -14,8 +14,17 @@
 // method with fixed steps, differentiating the scheme equals applying the scheme to the variational equations):
 //
 //     parameters theta = [u_k (m), t_k, dt_k, u_{k+1} (m, order 1 only)]   -- the state x_k enters linearly through Phi
-//     columns          x, Phi (n), x_b (p), Phi_b (n p), x_ab (p (p+1) / 2),          each of length n
+//     forward columns  x, Phi (n; Jacobian calls only), x_b (p), x_ab (p (p+1) / 2; Hessian calls only),   each of length n
 //     right-hand side  (M y)_0 = M0 y0,  (M y)_b = M0 y_b + M_b y0,  (M y)_ab = M0 y_ab + M_a y_b + M_b y_a + M_ab y0
+//
+// The (x, theta) block of the Hessian of mu' f is -d(Phi' mu)/dtheta.  Round 3: instead of carrying the n p columns Phi_b
+// forward (1536 matrix-vector products per RK4 step at 32 states, p = 6), the kernel runs the DISCRETE ADJOINT of the scheme:
+// the step is a linear map y+ = R y (the ODE is linear in the state), so lambda = Phi' mu = R_1' R_2' ... R_S' mu is a backward
+// recursion through the same stages with transposed matrices -- it needs no stored trajectory -- and its parameter
+// sensitivities lambda_b ride along (1 + 2 p products per stage).  52 instead of 1536 products per step for that block; the
+// (theta, theta) block keeps the forward second-order columns x_ab.  Per stage, backward (k4 first):
+//     kbar_4 = h/6 w,  kbar_3 = h/3 w + h M4' kbar_4,  kbar_2 = h/3 w + h/2 M2' kbar_3,  kbar_1 = h/6 w + h/2 M2' kbar_2,
+//     w- = w + M4' kbar_4 + M2' kbar_3 + M2' kbar_2 + M1' kbar_1          (and the product rule for the b-derivatives)
 //
 // where M = dt_k G(u(tau), t) and its parameter derivatives M_b, M_ab are linear combinations of the shared matrices G_j, H_cj
 // (formed once per stage).  Outputs are the per-interval dense blocks of a generic integrator -- defect (n), Jacobian block
@@ -31,6 +40,8 @@ namespace dto {
 namespace {
 
 constexpr int TDB_MAX_COEFS = 6144;  // (1 + p + p (p+1)/2) * (m+1) * (1 + nmod) must fit (checked by tdb_supported)
+
+__host__ __device__ inline bool tdb_uses_adjoint(int n) { return n >= 12; }
 
 __device__ __forceinline__ int pair_idx(int a, int b, int p) {  // a <= b < p, row-major upper triangle
     return a * p - a * (a - 1) / 2 + (b - a);
@@ -59,10 +70,16 @@ __global__ void __launch_bounds__(256) k_tdb(TdbArgs a) {
     const double* zk1 = zk + z;
     const double tk = zk[a.T.t_off], dt = zk[a.P.dt_idx];
     const int tid = threadIdx.x;
-    // column layout
-    const int c_x = 0, c_phi = 1, c_xb = 1 + n, c_phib = 1 + n + p, c_xab = 1 + n + p + n * p;
-    const int C = need == 0 ? 1 : (need == 1 ? 1 + n + p : 1 + n + p + n * p + p * (p + 1) / 2);
-    const int nM = need == 0 ? 1 : (need == 1 ? 1 + p : 1 + p + p * (p + 1) / 2);
+    const int P2 = p * (p + 1) / 2;
+    // forward column layout: x | Phi (Jacobian calls; small-state Hessian calls) | x_b | Phi_b (small-state Hessian calls) | x_ab
+    // (Hessian calls).  The (x, theta) block of a Hessian call comes from the discrete adjoint (below) from 12 states on; below,
+    // the n p forward columns Phi_b are cheaper than a second pass through the stages (4 states x 1000 knots: 1.8 against 2.2 ms)
+    const bool adjoint = need == 2 && tdb_uses_adjoint(n);
+    const int nphi = (need == 1 || (need == 2 && !adjoint)) ? n : 0;
+    const int nphib = (need == 2 && !adjoint) ? n * p : 0;
+    const int c_x = 0, c_phi = 1, c_xb = 1 + nphi, c_phib = 1 + nphi + p, c_xab = 1 + nphi + p + nphib;
+    const int C = need == 0 ? 1 : (need == 1 ? 1 + n + p : 1 + nphi + p + nphib + P2);
+    const int nM = need == 0 ? 1 : (need == 1 ? 1 + p : 1 + p + P2);
     double* S = a.scratch + (int64_t)blockIdx.x * a.scratch_stride;
     double* Y = S;
     double* ACC = Y + (int64_t)C * n;
@@ -74,12 +91,80 @@ __global__ void __launch_bounds__(256) k_tdb(TdbArgs a) {
     auto Bq = [&](int j, int c) { return c == 0 ? a.T.G + (int64_t)j * nn : a.T.H + ((int64_t)(c - 1) * (m + 1) + j) * nn; };
     __shared__ double coefs[TDB_MAX_COEFS];  // [nM][Q] scalar coefficient of B_q in each jet of M at the current stage time
 
+    // jets of M(tau) = dt * sum_j a_j(tau) (G_j + sum_c phi_c(t) H_cj),  t = t_k + tau dt: first the scalar coefficient of
+    // every shared matrix B_q in every jet (value / first / second derivative), then the matrices; `njet` jets are formed
+    auto form_jets = [&](double tau, int njet) {
+        for (int e = tid; e < njet * Q; e += 256) {
+            const int which = e / Q, q = e - which * Q;
+            const int j = q / (1 + nmod), c = q - j * (1 + nmod);
+            // which: 0 value; 1 + b first derivative; 1 + p + pair(a, b) second derivative
+            int b1 = -1, b2 = -1;
+            if (which >= 1 && which <= p) b1 = which - 1;
+            else if (which > p) {
+                int rem = which - 1 - p, aa = 0;
+                while (rem >= p - aa) { rem -= p - aa; ++aa; }
+                b1 = aa; b2 = aa + rem;
+            }
+            // a_j and its derivative slots: wk = d a_j / d u_kj, wk1 = d a_j / d u_{k+1,j}
+            double aj = 1.0, wk = 0.0, wk1 = 0.0;
+            if (j >= 1) {
+                const double uk = zk[a.T.u_off + j - 1];
+                if (order) { const double uk1 = zk1[a.T.u_off + j - 1]; aj = (1.0 - tau) * uk + tau * uk1; wk = 1.0 - tau; wk1 = tau; }
+                else { aj = uk; wk = 1.0; }
+            }
+            double ph = 1.0, ph1 = 0.0, ph2 = 0.0;
+            if (c >= 1) {
+                const double om = a.T.mod_omega[c - 1], arg = om * (tk + tau * dt);
+                const double cs = cos(arg), sn = sin(arg);
+                if (a.T.mod_kind[c - 1] == 1) { ph = cs; ph1 = -om * sn; ph2 = -om * om * cs; }
+                else { ph = sn; ph1 = om * cs; ph2 = -om * om * sn; }
+            }
+            // s = dt * a_j * phi(t_k + tau dt) and its derivatives; parameter classes: 0 = u_k (drive jj), 1 = t, 2 = dt,
+            // 3 = u_{k+1} (drive jj)
+            auto cls = [&](int b, int& jj) { if (b < m) { jj = b + 1; return 0; } if (b == m) { jj = -1; return 1; }
+                                             if (b == m + 1) { jj = -1; return 2; } jj = b - m - 1; return 3; };
+            double coef;
+            if (which == 0) coef = dt * aj * ph;
+            else if (b2 < 0) {
+                int jj; const int k1 = cls(b1, jj);
+                if (k1 == 0) coef = jj == j ? dt * wk * ph : 0.0;
+                else if (k1 == 3) coef = jj == j ? dt * wk1 * ph : 0.0;
+                else if (k1 == 1) coef = dt * aj * ph1;
+                else coef = aj * ph + dt * aj * tau * ph1;
+            } else {
+                int j1, j2; const int k1 = cls(b1, j1), k2 = cls(b2, j2);
+                const bool u1 = k1 == 0 || k1 == 3, u2 = k2 == 0 || k2 == 3;
+                if (u1 && u2) coef = 0.0;
+                else if (u1 || u2) {
+                    const int ju = u1 ? j1 : j2, ku = u1 ? k1 : k2, ko = u1 ? k2 : k1;
+                    const double w = ku == 0 ? wk : wk1;
+                    if (ju != j) coef = 0.0;
+                    else coef = ko == 1 ? dt * w * ph1 : w * (ph + dt * tau * ph1);
+                } else if (k1 == 1 && k2 == 1) coef = dt * aj * ph2;
+                else if (k1 == 2 && k2 == 2) coef = 2.0 * aj * tau * ph1 + dt * aj * tau * tau * ph2;
+                else coef = aj * ph1 + dt * aj * tau * ph2;   // (t, dt)
+            }
+            coefs[e] = coef;
+        }
+        __syncthreads();
+        for (int e = tid; e < njet * nn; e += 256) {
+            const int which = e / nn, off = e - which * nn;
+            double acc = 0.0;
+            for (int q = 0; q < Q; ++q) {
+                const double cf = coefs[which * Q + q];
+                if (cf != 0.0) acc += cf * Bq(q / (1 + nmod), q % (1 + nmod))[off];
+            }
+            MJ[e] = acc;
+        }
+        __syncthreads();
+    };
+
     // initial values: x = x_k, Phi = I, everything else 0
     for (int e = tid; e < C * n; e += 256) {
         const int c = e / n, r = e - c * n;
         double v = 0.0;
         if (c == c_x) v = zk[a.T.x_off + r];
-        else if (need >= 1 && c >= c_phi && c < c_phi + n) v = (c - c_phi == r) ? 1.0 : 0.0;
+        else if (nphi && c >= c_phi && c < c_phi + n) v = (c - c_phi == r) ? 1.0 : 0.0;
         Y[e] = v;
     }
     __syncthreads();
@@ -89,71 +174,7 @@ __global__ void __launch_bounds__(256) k_tdb(TdbArgs a) {
         for (int stage = 0; stage < 4; ++stage) {
             const double tau = (step + (stage == 0 ? 0.0 : (stage == 3 ? 1.0 : 0.5))) * h;
             const double* IN = stage == 0 ? Y : (stage == 2 ? TB : TA);
-            // ---- jets of M(tau) = dt * sum_j a_j(tau) (G_j + sum_c phi_c(t) H_cj),  t = t_k + tau dt: first the scalar
-            // coefficient of every shared matrix B_q in every jet (value / first / second derivative), then the matrices
-            for (int e = tid; e < nM * Q; e += 256) {
-                const int which = e / Q, q = e - which * Q;
-                const int j = q / (1 + nmod), c = q - j * (1 + nmod);
-                // which: 0 value; 1 + b first derivative; 1 + p + pair(a, b) second derivative
-                int b1 = -1, b2 = -1;
-                if (which >= 1 && which <= p) b1 = which - 1;
-                else if (which > p) {
-                    int rem = which - 1 - p, aa = 0;
-                    while (rem >= p - aa) { rem -= p - aa; ++aa; }
-                    b1 = aa; b2 = aa + rem;
-                }
-                // a_j and its derivative slots: wk = d a_j / d u_kj, wk1 = d a_j / d u_{k+1,j}
-                double aj = 1.0, wk = 0.0, wk1 = 0.0;
-                if (j >= 1) {
-                    const double uk = zk[a.T.u_off + j - 1];
-                    if (order) { const double uk1 = zk1[a.T.u_off + j - 1]; aj = (1.0 - tau) * uk + tau * uk1; wk = 1.0 - tau; wk1 = tau; }
-                    else { aj = uk; wk = 1.0; }
-                }
-                double ph = 1.0, ph1 = 0.0, ph2 = 0.0;
-                if (c >= 1) {
-                    const double om = a.T.mod_omega[c - 1], arg = om * (tk + tau * dt);
-                    const double cs = cos(arg), sn = sin(arg);
-                    if (a.T.mod_kind[c - 1] == 1) { ph = cs; ph1 = -om * sn; ph2 = -om * om * cs; }
-                    else { ph = sn; ph1 = om * cs; ph2 = -om * om * sn; }
-                }
-                // s = dt * a_j * phi(t_k + tau dt) and its derivatives; parameter classes: 0 = u_k (drive jj), 1 = t, 2 = dt,
-                // 3 = u_{k+1} (drive jj)
-                auto cls = [&](int b, int& jj) { if (b < m) { jj = b + 1; return 0; } if (b == m) { jj = -1; return 1; }
-                                                 if (b == m + 1) { jj = -1; return 2; } jj = b - m - 1; return 3; };
-                double coef;
-                if (which == 0) coef = dt * aj * ph;
-                else if (b2 < 0) {
-                    int jj; const int k1 = cls(b1, jj);
-                    if (k1 == 0) coef = jj == j ? dt * wk * ph : 0.0;
-                    else if (k1 == 3) coef = jj == j ? dt * wk1 * ph : 0.0;
-                    else if (k1 == 1) coef = dt * aj * ph1;
-                    else coef = aj * ph + dt * aj * tau * ph1;
-                } else {
-                    int j1, j2; const int k1 = cls(b1, j1), k2 = cls(b2, j2);
-                    const bool u1 = k1 == 0 || k1 == 3, u2 = k2 == 0 || k2 == 3;
-                    if (u1 && u2) coef = 0.0;
-                    else if (u1 || u2) {
-                        const int ju = u1 ? j1 : j2, ku = u1 ? k1 : k2, ko = u1 ? k2 : k1;
-                        const double w = ku == 0 ? wk : wk1;
-                        if (ju != j) coef = 0.0;
-                        else coef = ko == 1 ? dt * w * ph1 : w * (ph + dt * tau * ph1);
-                    } else if (k1 == 1 && k2 == 1) coef = dt * aj * ph2;
-                    else if (k1 == 2 && k2 == 2) coef = 2.0 * aj * tau * ph1 + dt * aj * tau * tau * ph2;
-                    else coef = aj * ph1 + dt * aj * tau * ph2;   // (t, dt)
-                }
-                coefs[e] = coef;
-            }
-            __syncthreads();
-            for (int e = tid; e < nM * nn; e += 256) {
-                const int which = e / nn, off = e - which * nn;
-                double acc = 0.0;
-                for (int q = 0; q < Q; ++q) {
-                    const double cf = coefs[which * Q + q];
-                    if (cf != 0.0) acc += cf * Bq(q / (1 + nmod), q % (1 + nmod))[off];
-                }
-                MJ[e] = acc;
-            }
-            __syncthreads();
+            if (stage != 2) form_jets(tau, nM);   // stages 1 and 2 share their time
             // ---- K = F(IN), then the RK4 update of this stage
             const double* M0 = MJ;
             double* OUT = stage == 0 ? TA : (stage == 1 ? TB : (stage == 2 ? TA : Y));
@@ -169,7 +190,7 @@ __global__ void __launch_bounds__(256) k_tdb(TdbArgs a) {
                 };
                 double K = mv(M0, c);
                 if (need >= 1 && c >= c_xb && c < c_xb + p) K += mv(MJ + (int64_t)(1 + c - c_xb) * nn, c_x);
-                else if (need >= 2 && c >= c_phib && c < c_phib + n * p) {
+                else if (nphib && c >= c_phib && c < c_phib + nphib) {
                     const int b = (c - c_phib) / n, i = (c - c_phib) - b * n;
                     K += mv(MJ + (int64_t)(1 + b) * nn, c_phi + i);
                 } else if (need >= 2 && c >= c_xab) {
@@ -192,44 +213,104 @@ __global__ void __launch_bounds__(256) k_tdb(TdbArgs a) {
     for (int r = tid; r < n; r += 256) a.vals[kn * n + r] = zk1[a.T.x_off + r] - Y[c_x * n + r];
     if (need < 1) return;
     auto zz_of = [&](int b) { return b < m ? a.T.u_off + b : (b == m ? a.T.t_off : (b == m + 1 ? a.P.dt_idx : z + a.T.u_off + (b - m - 2))); };
-    double* J = a.jac + kn * (int64_t)n * 2 * z;
-    for (int e = tid; e < n * 2 * z; e += 256) J[e] = 0.0;
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, r = e - i * n;
-        J[(int64_t)(a.T.x_off + i) * n + r] = -Y[(int64_t)(c_phi + i) * n + r];
+    if (need == 1) {
+        double* J = a.jac + kn * (int64_t)n * 2 * z;
+        for (int e = tid; e < n * 2 * z; e += 256) J[e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, r = e - i * n;
+            J[(int64_t)(a.T.x_off + i) * n + r] = -Y[(int64_t)(c_phi + i) * n + r];
+        }
+        for (int r = tid; r < n; r += 256) J[(int64_t)(z + a.T.x_off + r) * n + r] = 1.0;
+        __syncthreads();
+        // parameter columns ADD (a component may serve twice, e.g. the timestep listed as the time variable)
+        if (tid < n)
+            for (int b = 0; b < p; ++b) J[(int64_t)zz_of(b) * n + tid] -= Y[(int64_t)(c_xb + b) * n + tid];
+        return;
     }
-    for (int r = tid; r < n; r += 256) J[(int64_t)(z + a.T.x_off + r) * n + r] = 1.0;
-    __syncthreads();
-    // parameter columns ADD (a component may serve twice, e.g. the timestep listed as the time variable)
-    if (tid < n)
-        for (int b = 0; b < p; ++b) J[(int64_t)zz_of(b) * n + tid] -= Y[(int64_t)(c_xb + b) * n + tid];
-    if (need < 2) return;
-    double* Hb = a.hess + kn * (int64_t)4 * z * z;
-    for (int e = tid; e < 4 * z * z; e += 256) Hb[e] = 0.0;
-    __syncthreads();
+
     const double* muk = a.mu + a.T.row_off + kn * n;
     const int ld = 2 * z;
-    // (x_i, theta_b): -mu' dPhi_i/dtheta_b;  (theta_a, theta_b): -mu' x_ab.  One thread per entry; entries that land on the
-    // same (row, col) of the block (coinciding components) are added by the same thread order-independently via atomics.
+    double* Hb = a.hess + kn * (int64_t)4 * z * z;
+    auto theta_block = [&]() {   // (theta_a, theta_b): -mu' x_ab.  Entries that land on the same (row, col) meet by atomics
+        for (int e = tid; e < P2; e += 256) {
+            int rem = e, aa = 0;
+            while (rem >= p - aa) { rem -= p - aa; ++aa; }
+            const int bb = aa + rem;
+            double s = 0.0;
+            for (int r = 0; r < n; ++r) s += muk[r] * Y[(int64_t)(c_xab + e) * n + r];
+            const int ra = zz_of(aa), rb = zz_of(bb);
+            atomicAdd(&Hb[ra + (int64_t)ld * rb], -s);
+            if (aa != bb) atomicAdd(&Hb[rb + (int64_t)ld * ra], -s);
+        }
+    };
+    if (!adjoint) {
+        // small state: (x_i, theta_b) = -mu' dPhi_i/dtheta_b from the forward columns Phi_b
+        for (int e = tid; e < 4 * z * z; e += 256) Hb[e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < n * p; e += 256) {
+            const int b = e / n, i = e - b * n;
+            double s = 0.0;
+            for (int r = 0; r < n; ++r) s += muk[r] * Y[(int64_t)(c_phib + b * n + i) * n + r];
+            const int ri = a.T.x_off + i, cb = zz_of(b);
+            atomicAdd(&Hb[ri + (int64_t)ld * cb], -s);
+            atomicAdd(&Hb[cb + (int64_t)ld * ri], -s);
+        }
+        theta_block();
+        return;
+    }
+    // ---- Hessian call: discrete adjoint lambda = Phi' mu and its parameter sensitivities lambda_b, backward through the steps.
+    // Columns 0 .. p of W: lambda, lambda_b.  The forward arrays are free now (Y keeps x_ab for the (theta, theta) block).
+    const int CA = 1 + p;
+    double* W = TA;                              // current adjoint columns
+    double* WN = TB;                             // w- being accumulated
+    double* KB = ACC;                            // kbar of the stage at hand
+    double* UB = ACC + (int64_t)CA * n;          // ubar = M' kbar (and product rule)
+    for (int e = tid; e < CA * n; e += 256) W[e] = e < n ? muk[e] : 0.0;
+    __syncthreads();
+    for (int step = a.T.substeps - 1; step >= 0; --step) {
+        for (int e = tid; e < CA * n; e += 256) WN[e] = W[e];
+        // stage 3 (k4, time tau + h), stages 2 and 1 (k3, k2, time tau + h/2), stage 0 (k1, time tau)
+        for (int stage = 3; stage >= 0; --stage) {
+            const double tau = (step + (stage == 0 ? 0.0 : (stage == 3 ? 1.0 : 0.5))) * h;
+            if (stage != 1) form_jets(tau, CA);   // stages 2 and 1 share their time (form_jets ends with a barrier)
+            // kbar of this stage from w and the previous stage's ubar
+            const double cw = (stage == 3 || stage == 0) ? h / 6.0 : h / 3.0;
+            const double cu = stage == 3 ? 0.0 : (stage == 2 ? h : 0.5 * h);
+            for (int e = tid; e < CA * n; e += 256) KB[e] = cw * W[e] + (cu != 0.0 ? cu * UB[e] : 0.0);
+            __syncthreads();
+            // ubar_c = M' kbar_c (+ M_b' kbar_0 for the sensitivity columns)
+            for (int e = tid; e < CA * n; e += 256) {
+                const int c = e / n, r = e - c * n;
+                auto mvT = [&](const double* M, int col) {   // (M' * KB[col])[r] = column r of M . KB[col]
+                    double s = 0.0;
+                    const double* y = KB + (int64_t)col * n;
+                    const double* mc = M + (int64_t)r * n;
+                    for (int k = 0; k < n; ++k) s += mc[k] * y[k];
+                    return s;
+                };
+                double u = mvT(MJ, c);
+                if (c >= 1) u += mvT(MJ + (int64_t)c * nn, 0);
+                UB[e] = u;   // (KB is read, UB written: no hazard inside this loop; UB's old values were consumed above)
+                WN[e] += u;
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < CA * n; e += 256) W[e] = WN[e];
+        __syncthreads();
+    }
+
+    for (int e = tid; e < 4 * z * z; e += 256) Hb[e] = 0.0;
+    __syncthreads();
+    // (x_i, theta_b): -d lambda_i / d theta_b, one thread per entry
     for (int e = tid; e < n * p; e += 256) {
         const int b = e / n, i = e - b * n;
-        double s = 0.0;
-        for (int r = 0; r < n; ++r) s += muk[r] * Y[(int64_t)(c_phib + b * n + i) * n + r];
+        const double s = W[(int64_t)(1 + b) * n + i];
         const int ri = a.T.x_off + i, cb = zz_of(b);
         atomicAdd(&Hb[ri + (int64_t)ld * cb], -s);
         atomicAdd(&Hb[cb + (int64_t)ld * ri], -s);
     }
-    for (int e = tid; e < p * (p + 1) / 2; e += 256) {
-        int rem = e, aa = 0;
-        while (rem >= p - aa) { rem -= p - aa; ++aa; }
-        const int bb = aa + rem;
-        double s = 0.0;
-        for (int r = 0; r < n; ++r) s += muk[r] * Y[(int64_t)(c_xab + e) * n + r];
-        const int ra = zz_of(aa), rb = zz_of(bb);
-        atomicAdd(&Hb[ra + (int64_t)ld * rb], -s);
-        if (aa != bb) atomicAdd(&Hb[rb + (int64_t)ld * ra], -s);
-    }
+    theta_block();
 }
 
 }  // namespace
@@ -242,7 +323,8 @@ bool tdb_supported(const KTdb& T) {
 
 size_t tdb_scratch_doubles(const KTdb& T, int need) {
     const int n = T.n, m = T.m, p = m + 2 + (T.order ? m : 0);
-    const size_t C = need == 0 ? 1 : (need == 1 ? 1 + n + p : 1 + n + p + (size_t)n * p + (size_t)p * (p + 1) / 2);
+    const size_t P2 = (size_t)p * (p + 1) / 2;
+    const size_t C = need == 0 ? 1 : (need == 1 ? 1 + n + p : (tdb_uses_adjoint(n) ? 1 + p + P2 : 1 + n + p + (size_t)n * p + P2));
     const size_t nM = need == 0 ? 1 : (need == 1 ? 1 + p : 1 + p + (size_t)p * (p + 1) / 2);
     return 4 * C * n + nM * (size_t)n * n;
 }
