@@ -519,6 +519,25 @@ def main():
             torch.cuda.synchronize(dev)
             step_ms.append((time.perf_counter() - t0) * 1e3)
 
+    # The same K steps into a BOUND output vector (dto_bind_output_dev: what a solver in GPU mode, which hands the engine the same
+    # device vector every iteration, can declare): the call-invariant half of the slab is then written once, not per call.
+    # Reported next to `value`, never as `value` -- the headline keeps the reference's semantics (every entry written per call).
+    bound_block = None
+    if args.callback in ("jacobian", "hessian") and world == 1:
+        vec = dto_amd.capi.VECTOR_JACOBIAN if args.callback == "jacobian" else dto_amd.capi.VECTOR_HESSIAN
+        ev.bind_output_dev(vec, out.data_ptr())
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        tb = time.perf_counter() - t0
+        ev.bind_output_dev(vec, 0)
+        bound_block = {"ms_per_step": tb / args.steps * 1e3, "knot_points_per_s": N_total * args.steps / tb,
+                       "note": "dto_bind_output_dev: constants (structural zeros, identity blocks) written once; same buffer every call"}
+
     traffic, traffic_src, traffic_call = None, None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
         import glob
@@ -595,6 +614,8 @@ def main():
             ss = sorted(step_ms)
             line["ms_per_step_median"] = ss[len(ss) // 2] if len(ss) % 2 else 0.5 * (ss[len(ss) // 2 - 1] + ss[len(ss) // 2])
             line["value_from_median"] = N_total / (line["ms_per_step_median"] * 1e-3)
+        if bound_block is not None:
+            line["bound_output"] = bound_block
         if gather is not None:
             line["gather"] = gather
         if strong_block is not None:

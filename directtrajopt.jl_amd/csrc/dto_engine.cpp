@@ -186,6 +186,17 @@ struct dto_handle {
     int xfer_cap = 0;                                         // host-pointer Jacobian: chain chunk (intervals) for the early hand-over, 0 = off
     std::function<void(int64_t, int)> on_chain_chunk;         // ... and its hook: (first local interval, count) of a finished chunk
     bool plans_built = false;
+    bool raw_plans_built = false;
+    // dto_bind_output_dev: a device buffer the caller passes again and again (MadNLP's value vectors in GPU mode).  Once a call
+    // has written it in full ("primed"), later calls into the SAME pointer leave the call-invariant entries alone -- structural
+    // zeros, the identity z_{k+1} halves: half of a Jacobian slab, 99 % of a Hessian slab -- and clear only the runs a kernel
+    // accumulates into.  [0] Jacobian, [1] Hessian.
+    double* bound[2] = {nullptr, nullptr};
+    bool primed[2] = {false, false};
+    int64_t* d_bind_start[2] = {nullptr, nullptr};
+    int64_t* d_bind_len[2] = {nullptr, nullptr};
+    int64_t n_bind_runs[2] = {0, 0};
+    bool bind_ready[2] = {false, false};
     int host_xfer = 1;
     int xfer_check = 0;  // option "host_xfer_check": every host-pointer Jacobian / Hessian is compared with the whole device slab
     std::vector<ExtObjHost> ext_obj;
@@ -567,6 +578,7 @@ int fused_sweep_steps(dto_handle* h, const SweepBuf& w, int d_ub, hipStream_t st
 bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store);
 bool cluster_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
                            ClusterSweepPlan& cp);
+bool ensure_bind_runs(dto_handle* h, int which);
 
 // Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
@@ -1136,7 +1148,10 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
     // overwrites all of it
     // (enqueued inside the chain, where it fills the GPU while the host waits for the scaling decision)
     const bool lone = h->bil.size() == 1 && h->P.n_int > 0 && !h->bil[0].small;
-    if (!lone) HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
+    // bound and primed output (dto_bind_output_dev): constants are in place, clear only the runs kernels accumulate into
+    const bool keep_constants = h->bound[0] == dvals && h->primed[0] && ensure_bind_runs(h, 0);
+    if (keep_constants) launch_zero_runs(st, h->d_bind_start[0], h->d_bind_len[0], h->n_bind_runs[0], dvals);
+    else if (!lone) HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
     h->last_terms = 0;
     const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
@@ -1190,7 +1205,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
                 if (keep || plan.q > 1) b.p_terms = false;  // the store now holds every column type / the scale factors changed
-            }, [&] { if (lone) launch_jac_zero(st, h->P, b.k, dvals); });
+            }, [&] { if (lone && !keep_constants) launch_jac_zero(st, h->P, b.k, dvals); });
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_join, ss));
                 HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1209,7 +1224,10 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
 }
 
 void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dH, hipStream_t st) {
-    HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, st));  // fill!(H, 0), evaluator.jl:571
+    if (h->bound[1] == dH && h->primed[1] && ensure_bind_runs(h, 1))   // bound output: structural zeros are in place
+        launch_zero_runs(st, h->d_bind_start[1], h->d_bind_len[1], h->n_bind_runs[1], dH);
+    else
+        HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, st));  // fill!(H, 0), evaluator.jl:571
     const bool same = same_point(h, dZ, st);
     // integrators in reference order (evaluator.jl:574-598)
     for (size_t i = 0; i < h->integ_kind.size(); ++i) {
@@ -1473,12 +1491,42 @@ void build_hess_plan(dto_handle* h) {
     if (h->k_hi == h->N) var(h->hess_block_nnz - P.hess_lo, (int64_t)h->tail_rows.size());  // global-column tail
 }
 
+void build_raw_plans(dto_handle* h) {
+    if (h->raw_plans_built) return;
+    h->raw_plans_built = true;
+    build_jac_plan(h);
+    if (h->eval_hessian) build_hess_plan(h);
+}
+
+// Bound outputs: the variable runs a callback must clear itself when the full zero-fill is skipped -- every run of the plan except
+// the -E_k blocks, which the propagator chain overwrites entry by entry ("early" runs).
+bool ensure_bind_runs(dto_handle* h, int which) {
+    if (h->bind_ready[which]) return h->n_bind_runs[which] >= 0;
+    h->bind_ready[which] = true;
+    build_raw_plans(h);
+    const XferPlan& p = which == 0 ? h->jac_plan : h->hess_plan;
+    h->n_bind_runs[which] = -1;
+    if (p.total <= 0) return false;
+    std::vector<int64_t> st, ln;
+    int64_t var_total = 0;
+    for (size_t r = 0; r < p.start.size(); ++r) {
+        var_total += p.len[r];
+        if (!p.early.empty() && p.early[r] >= 0) continue;
+        st.push_back(p.start[r]);
+        ln.push_back(p.len[r]);
+    }
+    if (var_total * 10 > p.total * 9) return false;  // (nearly) everything varies: the plain zero-fill is as good
+    h->d_bind_start[which] = own(h, dupload(st));
+    h->d_bind_len[which] = own(h, dupload(ln));
+    h->n_bind_runs[which] = (int64_t)st.size();
+    return true;
+}
+
 void ensure_plans(dto_handle* h) {
     if (h->plans_built) return;
     h->plans_built = true;
     if (!h->host_xfer) return;
-    build_jac_plan(h);
-    if (h->eval_hessian) build_hess_plan(h);
+    build_raw_plans(h);
     for (XferPlan* p : {&h->jac_plan, &h->hess_plan}) {
         if (p->total <= 0) continue;
         p->finalize(h->P.n_int, HostXfer::CHUNK_DOUBLES);
@@ -1503,6 +1551,7 @@ double* staging(dto_handle* h, size_t n) {
 void drop_caches(dto_handle* h) {
     for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
 }
+void unprime(dto_handle* h) { h->primed[0] = h->primed[1] = false; }
 
 // Enqueue, behind the kernels of an asynchronous call, the copy of every sweep's statistics to pinned memory.
 void enqueue_stats(dto_handle* h, hipStream_t st) {
@@ -2384,12 +2433,16 @@ int dto_eval_constraint_dev(dto_handle* h, const double* dZ, double* dg, void* s
     return guarded(h, [&] { do_constraint(h, dZ, dg, (hipStream_t)stream); }, G_ASYNC, (hipStream_t)stream);
 }
 int dto_eval_jacobian_dev(dto_handle* h, const double* dZ, double* dvals, void* stream) {
-    return guarded(h, [&] { do_jacobian(h, dZ, dvals, (hipStream_t)stream); }, G_ASYNC, (hipStream_t)stream);
+    return guarded(h, [&] {
+        do_jacobian(h, dZ, dvals, (hipStream_t)stream);
+        if (h->bound[0] == dvals) h->primed[0] = true;
+    }, G_ASYNC, (hipStream_t)stream);
 }
 int dto_eval_hessian_dev(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dvals, void* stream) {
     return guarded(h, [&] {
         if (!h->eval_hessian) throw HipError{"handle was created with eval_hessian = 0"};
         do_hessian(h, dZ, sigma, dmu, dvals, (hipStream_t)stream);
+        if (h->bound[1] == dvals) h->primed[1] = true;
     }, G_ASYNC, (hipStream_t)stream);
 }
 
@@ -2674,6 +2727,15 @@ int dto_allreduce_objective_dev(dto_handle* h, double* df, void* stream) {
         const std::string e = h->comm->all_reduce_sum(df, 1, (hipStream_t)stream);
         if (!e.empty()) throw HipError{e};
     });
+}
+
+int dto_bind_output_dev(dto_handle* h, int32_t vector, double* dptr) {
+    if (!h) return fail(nullptr, "null handle");
+    if (vector != DTO_VECTOR_JACOBIAN && vector != DTO_VECTOR_HESSIAN) return fail(h, "dto_bind_output_dev: the Jacobian or the Hessian value vector");
+    const int w = vector == DTO_VECTOR_JACOBIAN ? 0 : 1;
+    h->bound[w] = dptr;
+    h->primed[w] = false;
+    return 0;
 }
 
 // ---- measurement

@@ -371,6 +371,7 @@ void launch_hess_bilinear(hipStream_t st, const KProb& P, const KBil& B, const S
                           const double* dmu, double* H, int with_uu);
 
 void launch_fill(hipStream_t st, double* p, int64_t n, double v);
+void launch_zero_runs(hipStream_t st, const int64_t* start, const int64_t* len, int64_t n_runs, double* dst);
 
 // Small-state path (dto_small.hip): one wavefront per interval, everything in LDS.  mode bits: 1 constraint
 // values, 2 Jacobian block, 4 Hessian block.  Gs = compact (m+1) x n x n generators.

@@ -99,6 +99,20 @@ void launch_pack_runs(hipStream_t st, const double* slab, const int64_t* start, 
     hipLaunchKernelGGL(k_pack_runs, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, st, slab, start, len, poff, n_runs, packed);
 }
 
+// dst[start[r] .. start[r] + len[r]) = 0 for every run: one wavefront per run (bound outputs: the runs kernels accumulate into)
+__global__ void __launch_bounds__(256) k_zero_runs(const int64_t* __restrict__ start, const int64_t* __restrict__ len, int64_t n_runs,
+                                                   double* __restrict__ dst) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_runs) return;
+    double* p = dst + start[r];
+    const int64_t n = len[r];
+    for (int64_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0.0;
+}
+void launch_zero_runs(hipStream_t st, const int64_t* start, const int64_t* len, int64_t n_runs, double* dst) {
+    if (n_runs <= 0) return;
+    hipLaunchKernelGGL(k_zero_runs, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, st, start, len, n_runs, dst);
+}
+
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n) {
     if (n <= 0) return;
     int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -1737,10 +1751,23 @@ __global__ void k_jac_derivative(KProb P, KDer D, const double* __restrict__ Z, 
     const int64_t kn = P.kn_lo + kl;
     if (kn >= 1) vals[jac_pos(P, P.colptr, kn, D.x_off + r, D.pre, D.d, 0, r)] = 1.0;
     if (kn < P.K) {
+        // row r of the interval's block has three entries: d/dx_r = -1, d/dxdot_r = -dt, d/ddt = -xdot_r.  Components may
+        // coincide (x and xdot overlapping, the timestep inside one of them): such contributions add, as they do inside the
+        // reference's single ForwardDiff Jacobian of the block -- combined HERE and then ASSIGNED, so that the entry does not
+        // depend on what the buffer held before (bound outputs keep their constants; no other thread or kernel writes row r of
+        // this integrator)
         const double* zk = Z + kn * P.z;
-        atomicAdd(&vals[jac_pos(P, P.colptr, kn, D.x_off + r, D.pre, D.d, 1, r)], -1.0);
-        atomicAdd(&vals[jac_pos(P, P.colptr, kn, D.xdot_off + r, D.pre, D.d, 1, r)], -zk[P.dt_idx]);
-        atomicAdd(&vals[jac_pos(P, P.colptr, kn, P.dt_idx, D.pre, D.d, 1, r)], -zk[D.xdot_off + r]);
+        const int64_t p1 = jac_pos(P, P.colptr, kn, D.x_off + r, D.pre, D.d, 1, r);
+        const int64_t p2 = jac_pos(P, P.colptr, kn, D.xdot_off + r, D.pre, D.d, 1, r);
+        const int64_t p3 = jac_pos(P, P.colptr, kn, P.dt_idx, D.pre, D.d, 1, r);
+        double v1 = -1.0, v2 = -zk[P.dt_idx], v3 = -zk[D.xdot_off + r];
+        bool w2 = true, w3 = true;
+        if (p2 == p1) { v1 += v2; w2 = false; }
+        if (p3 == p1) { v1 += v3; w3 = false; }
+        else if (p3 == p2 && w2) { v2 += v3; w3 = false; }
+        vals[p1] = v1;
+        if (w2) vals[p2] = v2;
+        if (w3) vals[p3] = v3;
     }
 }
 void launch_jac_derivative(hipStream_t st, const KProb& P, const KDer& Dv, const double* dZ, double* vals) {

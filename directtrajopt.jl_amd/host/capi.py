@@ -107,6 +107,7 @@ SYMBOLS = {
     "dto_gather_gradient_dev": (C.c_int, [H, C.c_void_p, C.c_void_p]),
     "dto_gather_constraint_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dto_allreduce_objective_dev": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+    "dto_bind_output_dev": (C.c_int, [H, C.c_int32, C.c_void_p]),
     "dto_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
     "dto_profile_enable": (C.c_int, [H, C.c_int32]),
     "dto_profile_reset": (C.c_int, [H]),

@@ -437,6 +437,11 @@ class Evaluator:
     def allreduce_objective_dev(self, df, stream=0):
         self._check(self._lib.dto_allreduce_objective_dev(self._h, df, stream))
 
+    def bind_output_dev(self, vector, dptr):
+        """dto_bind_output_dev: declare a device value vector (capi.VECTOR_JACOBIAN / VECTOR_HESSIAN) that later `*_dev` calls are
+        handed again and again; its call-invariant entries are then written once.  dptr = 0 unbinds."""
+        self._check(self._lib.dto_bind_output_dev(self._h, vector, dptr))
+
     def set_option(self, name, value):
         """dto_set_option: ``reuse_forward_sweep`` (solver loops evaluate g, J, H at the same point), ``expm_form``
         (0 = by cost, 2 / 3 = two- / three-product form of the Jacobian's matrix exponential)."""

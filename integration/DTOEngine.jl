@@ -621,6 +621,10 @@ function eval_hessian_lagrangian_dev!(ev::GPUEvaluator, dH::Ptr{Float64}, dZ::Pt
     check(ev, @ccall lib.dto_eval_hessian_dev(ev.handle::Ptr{Cvoid}, dZ::Ptr{Float64}, σ::Float64, dμ::Ptr{Float64}, dH::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
 end
 
+"Declare a device value vector (DTO_VECTOR_JACOBIAN / DTO_VECTOR_HESSIAN) that the `*_dev!` calls are handed every iteration: its call-invariant entries are then written once (include/dto_engine.h, bound outputs).  `C_NULL` unbinds."
+bind_output_dev!(ev::GPUEvaluator, vector::Int32, dptr::Ptr{Float64}) =
+    check(ev, @ccall lib.dto_bind_output_dev(ev.handle::Ptr{Cvoid}, vector::Int32, dptr::Ptr{Float64})::Cint)
+
 # ---- multi-GPU: one Julia process per GPU, `k_lo` / `k_hi` at construction; the engine owns the RCCL communicator --------------
 # (SURVEY.md section 8e; BASELINE configs[3]).  No callback needs a collective; these gather the per-rank value slabs for a
 # consumer that wants the whole vector on every GPU, and sum the objective's per-shard partial sums.

@@ -61,6 +61,13 @@ def _worker(rank, world, port, q):
             vec2[a:a + n] = local
             dto_amd.distributed.gather_slabs_inplace(vec2, layout, buffer=buf)
             ok &= bool(np.array_equal(vec2.numpy(), full[key]))
+            # ... and the asynchronous form (one in-place broadcast per rank, work handles waited on afterwards): what a rank with
+            # two engine handles uses to send one handle's slabs while the other computes
+            vec3 = torch.full((full[key].size,), float("nan"), dtype=torch.float64)
+            vec3[a:a + n] = local
+            for w in dto_amd.distributed.gather_slabs_async(vec3, layout):
+                w.wait()
+            ok &= bool(np.array_equal(vec3.numpy(), full[key]))
         # constraint rows: scatter the local buffer back through the row segments, then sum over ranks
         st, ln = ev.shard_rows()
         g = torch.zeros(ev.n_constraints, dtype=torch.float64)

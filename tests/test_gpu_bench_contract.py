@@ -35,7 +35,14 @@ def test_single_gpu_line():
     assert rf["timed_region"]["launches"] == rf["launches"]          # the serial pass repeats the timed region's launches
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
-    assert d["config"]["outputs_finite"] is True
+    assert d["config"]["outputs_finite"] is True and "HBM" in d["config"]["inputs"]
+    # median of individually fenced steps next to the mean `value` is; per-call traffic key; the Hessian's own roofline
+    assert d["ms_per_step_median"] > 0 and abs(d["value_from_median"] - 1200 / (d["ms_per_step_median"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "traffic_per_call" in rf
+    hr = d["other_callbacks"]["eval_hessian_lagrangian"]
+    assert hr["callback_hbm"]["algorithmic_bytes"] > 0
+    if "roofline" in hr:   # (64 states x 1200 knots: the adjoint sweep runs in the fused or the cluster form, both timed)
+        assert hr["roofline"]["bound"] == "mfma" and 0 < hr["roofline"]["frac"] < 1
 
 
 def test_gpus_2_without_torchrun_starts_two_ranks_itself():

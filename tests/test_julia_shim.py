@@ -67,7 +67,7 @@ def test_every_ccall_names_an_entry_point_with_the_right_argument_count():
     called = {name for name, _, _ in calls}
     # the device-resident callbacks (MadNLP GPU mode) and the engine's collectives are bound too
     for need in ("dto_eval_objective_dev", "dto_eval_gradient_dev", "dto_eval_constraint_dev", "dto_eval_jacobian_dev",
-                 "dto_eval_hessian_dev", "dto_comm_unique_id", "dto_comm_create", "dto_comm_destroy", "dto_get_gather_layout",
+                 "dto_eval_hessian_dev", "dto_bind_output_dev", "dto_comm_unique_id", "dto_comm_create", "dto_comm_destroy", "dto_get_gather_layout",
                  "dto_gather_jacobian_dev", "dto_gather_hessian_dev", "dto_gather_gradient_dev", "dto_gather_constraint_dev",
                  "dto_allreduce_objective_dev"):
         assert need in called, need
