@@ -265,7 +265,8 @@ struct GemmShapeP {
 
 template <class C, bool DMA_A>
 __device__ __forceinline__ void gemm_accumulate_p(GemmAccS<C>& acc, const double* __restrict__ A, int lda,
-                                                  const double* __restrict__ B, int ldb, int Klen, double* smem) {
+                                                  const double* __restrict__ B, int ldb, int Klen, double* smem,
+                                                  unsigned long long* prof = nullptr) {
     constexpr int TM = C::TM, KB = C::KB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WC, wn = wave % C::WC;
@@ -335,6 +336,20 @@ __device__ __forceinline__ void gemm_accumulate_p(GemmAccS<C>& acc, const double
                                                                              acc.v[ti][tj], 0, 0, 0);
             }
         }
+#ifdef DTO_TUNING
+        if (prof) {  // phase stamps (tools/stamp_analyze.py): cycles this wave waits for the next panel's loads, and at the barrier
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            if (kb + 1 < nkb) store_panel(buf ^ 1);
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            prof[0] += t1 - t0;
+            prof[1] += t3 - t2;
+            continue;
+        }
+#endif
         if (kb + 1 < nkb) store_panel(buf ^ 1);
         __syncthreads();
     }

@@ -21,6 +21,8 @@
 #include "dto_hostxfer.h"
 
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 namespace dto {
 
@@ -557,6 +559,10 @@ struct BGemmArgs {
     KBil Bi;
     int64_t int0;
     double* vals;
+#ifdef DTO_TUNING
+    int stamp_detail;             // 1: also the per-panel waits (perturbs the loop)
+    unsigned long long* stamps;   // phase stamps, 8 per tile (tools/stamp_analyze.py): HW_ID | XCC_ID << 32, cycles at start / loop end / end, 100 MHz ticks at start / end, cycles waiting for panel loads / at the loop barrier
+#endif
 };
 
 // Batched C_b = A_b * B_b over nbatch intervals, npad x npad x npad each (FP64 MFMA).
@@ -697,10 +703,35 @@ k_bgemm_p(BGemmArgs a) {
         const int tr = tile % tiles_r, tc = tile / tiles_r;
         const double* Ab = a.A + b * nn + (int64_t)tr * TM;
         const double* Bb = a.B + b * nn + (int64_t)tc * TN * a.npad;
+#ifdef DTO_TUNING
+        unsigned long long st0 = 0, st1 = 0, rt0 = 0;
+        if (a.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
         GemmAccS<Cfg> acc;
         acc.zero();
+#ifdef DTO_TUNING
+        unsigned long long waits[2] = {0, 0};
+        gemm_accumulate_p<Cfg, DMA_A>(acc, Ab, a.npad, Bb, a.npad, a.npad, smem, a.stamps && a.stamp_detail ? waits : nullptr);
+#else
         gemm_accumulate_p<Cfg, DMA_A>(acc, Ab, a.npad, Bb, a.npad, a.npad, smem);
+#endif
+#ifdef DTO_TUNING
+        if (a.stamps) st1 = __builtin_amdgcn_s_memtime();
+        struct StampAtExit {   // every path out of the tile body passes here
+            unsigned long long *dst, st0, st1, rt0, w0, w1;
+            __device__ ~StampAtExit() {
+                if (!dst) return;
+                __builtin_amdgcn_s_waitcnt(0);   // the tile's loads and stores have been issued and the loads are back
+                if (threadIdx.x == 0) {
+                    dst[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                             ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+                    dst[1] = st0; dst[2] = st1; dst[3] = __builtin_amdgcn_s_memtime(); dst[4] = rt0; dst[5] = __builtin_amdgcn_s_memrealtime();
+                    dst[6] = w0; dst[7] = w1;
+                }
+            }
+        } stamp_at_exit{a.stamps ? a.stamps + 8ll * v : nullptr, st0, st1, rt0, waits[0], waits[1]};
+#endif
 
         const int row0 = tr * TM + co.row_base, col0 = tc * TN + co.col_base;
         // -result into the Jacobian slab (x_k columns of the interval's own rows, evaluator.jl:514-525 /
@@ -805,10 +836,41 @@ static void launch_bgemm_shape(hipStream_t st, const BGemmArgs& a, int wgs_per_c
     }
     hipLaunchKernelGGL((k_bgemm<Cfg, EPI, false>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
 }
+#ifdef DTO_TUNING
+// DTO_STAMP_FILE=<path> DTO_STAMP_LAUNCH=<k>: launches k .. k+7 of the paired-core GEMM in this process record their phase stamps
+// into <path>.<launch>.epi<EPI> (tools/stamp_analyze.py)
+static unsigned long long* stamps_begin(hipStream_t st, const BGemmArgs& a, size_t& bytes, int& index) {
+    static int launches = 0;
+    static const int which = tune_int("DTO_STAMP_LAUNCH", -1);
+    index = launches++;
+    if (which < 0 || index < which || index >= which + 8 || !getenv("DTO_STAMP_FILE")) return nullptr;
+    bytes = 8ull * 8 * batch_tile_count(a.nbatch, (a.npad / 128) * (a.npad / 128));
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(d, 0, bytes, st);
+    return d;
+}
+static void stamps_end(hipStream_t st, unsigned long long* d, size_t bytes, int index, int epi) {
+    if (!d) return;
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h(bytes / 8);
+    (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+    const std::string path = std::string(getenv("DTO_STAMP_FILE")) + "." + std::to_string(index) + ".epi" + std::to_string(epi);
+    if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+    (void)hipFree(d);
+}
+#endif
 // paired-rows core: persistent for the plain products and the squarings (A by DMA), one workgroup per tile for the
 // polynomial products (their epilogues stream 3-4 more matrices; A through registers), as measured for the 8-byte core
 template <class Cfg, int EPI>
-static void launch_bgemm_p(hipStream_t st, const BGemmArgs& a) {
+static void launch_bgemm_p(hipStream_t st, const BGemmArgs& a_in) {
+    BGemmArgs a = a_in;
+#ifdef DTO_TUNING
+    size_t stamp_bytes = 0;
+    int stamp_index = 0;
+    a.stamps = stamps_begin(st, a, stamp_bytes, stamp_index);
+    a.stamp_detail = tune_int("DTO_STAMP_DETAIL", 0);
+#endif
     int grid = batch_tile_count(a.nbatch, (a.npad / Cfg::TM) * (a.npad / Cfg::TN));
     int wgs = bgemm_wgs_choice();
     if (wgs < 0) wgs = epi_poly(EPI) ? 0 : 2;
@@ -817,6 +879,9 @@ static void launch_bgemm_p(hipStream_t st, const BGemmArgs& a) {
     if (dma < 0) dma = epi_poly(EPI) ? 0 : 1;
     if (dma) hipLaunchKernelGGL((k_bgemm_p<Cfg, EPI, true>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
     else hipLaunchKernelGGL((k_bgemm_p<Cfg, EPI, false>), dim3(grid), dim3(Cfg::THREADS), 0, st, a);
+#ifdef DTO_TUNING
+    stamps_end(st, a.stamps, stamp_bytes, stamp_index, EPI);
+#endif
 }
 template <int EPI>
 static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
@@ -888,6 +953,7 @@ void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int
     }
     launch_bgemm<EPI_HORNER>(st, a);
 }
+
 void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
                          const KProb& P, const KBil& B, int64_t int0, double* vals) {
     BGemmArgs a{};

@@ -21,6 +21,18 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 #define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// "heavy" epilogue of probe #5: the two-output polynomial product's traffic (four matrices streamed in, two out), set by the host
+struct HeavyEpi { const double* M[4]; double* C2; int on; };
+__device__ HeavyEpi g_heavy;
+__device__ __forceinline__ void heavy_epilogue(d2 v, double* Cb_off, int64_t off_in_batch, int64_t boff) {
+    const HeavyEpi h = g_heavy;
+    const int64_t off = boff + off_in_batch;
+    const d2 m1 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(h.M[0] + off)), m2 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(h.M[1] + off)),
+             m3 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(h.M[2] + off)), m4 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(h.M[3] + off));
+    __builtin_nontemporal_store(v + 0.5 * m1 + 0.25 * m2 + 0.125 * m3 + 0.0625 * m4, reinterpret_cast<d2*>(Cb_off));
+    __builtin_nontemporal_store(v - 0.5 * m1 + 0.25 * m2 - 0.125 * m3 + 0.0625 * m4, reinterpret_cast<d2*>(h.C2 + off));
+}
+
 // ---------------------------------------------------------------------------------------------------- V0 (production copy)
 template <int MINW>
 __global__ void __launch_bounds__(256, MINW) k_v0(const double* A, const double* B, double* C, int npad, int nbatch) {
@@ -217,20 +229,25 @@ __global__ void __launch_bounds__(128 * WC_, MINW * WC_ / 2) k_v1(const double* 
 #pragma unroll
                 for (int p = 0; p < MT / 2; ++p) {
                     d2u vv = {acc[2 * p][tj][r], acc[2 * p + 1][tj][r]};
+                    if (pitch_off < 0) {   // heavy epilogue (probe #5)
+                        const int64_t o = (int64_t)(col0 + 16 * tj + 4 * r) * npad + row0 + 32 * p;
+                        heavy_epilogue(d2{vv.x, vv.y}, C + b * nn + o, o, b * nn);
+                        continue;
+                    }
                     __builtin_nontemporal_store(vv, reinterpret_cast<d2u*>(&Cb[(int64_t)(col0 + 16 * tj + 4 * r) * npad + row0 + 32 * p]));
                 }
     }
 }
 
 template <class K>
-double run(const char* name, K k, int threads, const double* A, const double* B, double* C, int npad, int nb, int wgs_per_cu, int reps, int extra = -1) {
+double run(const char* name, K k, int threads, const double* A, const double* B, double* C, int npad, int nb, int wgs_per_cu, int reps, int extra = -999) {
     const int tpm = (npad / 128) * (npad / 128), total = ((nb + 7) / 8) * 8 * tpm;
     const int grid = wgs_per_cu > 0 ? std::min(total, wgs_per_cu * 256) : total;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     auto launch = [&] {
-        if (extra >= 0) hipLaunchKernelGGL(k, dim3(grid), dim3(threads), 0, 0, A, B, C, npad, nb, extra);
+        if (extra != -999) hipLaunchKernelGGL(k, dim3(grid), dim3(threads), 0, 0, A, B, C, npad, nb, extra);
     };
     for (int w = 0; w < 3; ++w) launch();
     hipEventRecord(e0);
