@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (AMD datasheet). The microarch
 # guide lists no f64 MFMA figure; tools/mfma_f64_rate.py measures the issue rate on the box.
 HBM_PEAK_GBS = 8000.0
+WATCHDOG_S = int(os.environ.get("DTO_BENCH_WATCHDOG_S", "240"))  # limit for the multi-rank report blocks (gather, strong scaling)
 
 
 def baseline_metric():
@@ -489,6 +490,32 @@ def main():
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
 
+    # The blocks below are reports next to `value` (gather, strong scaling).  With several ranks they run collectives that
+    # have never executed on an 8-GPU node: should one of them hang, every rank leaves after WATCHDOG_S seconds and rank 0
+    # still prints the headline measured above (marked as such) instead of losing the line.
+    watchdog = None
+    if dist is not None and world > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                print(json.dumps({
+                    "metric": baseline_metric() if (args.callback, n, args.knots) == ("jacobian", 256, 2000)
+                    else f"knot-points/sec for eval_{args.callback}, {n}-state x {args.knots}-knot bilinear",
+                    "value": N_total * args.steps / elapsed, "unit": "knot-points/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                    "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                    "config": {"workload": f"configs[2]: {n}-state bilinear, {m} drives, N={N_total} knots over {world} GPU(s), "
+                                           f"callback={args.callback}", "knots_per_gpu": Nk, "knots_total": N_total,
+                               "parallelism": f"knot-range shards x{world}"},
+                    "watchdog": f"the gather / strong-scaling reports did not finish within {WATCHDOG_S} s; `value` is the "
+                                "compute-only headline measured before them"}), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(WATCHDOG_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
     gather = None
     want_gather = args.gather if args.gather is not None else world > 1
     if want_gather and dist is not None and args.callback in ("jacobian", "hessian"):
@@ -507,6 +534,9 @@ def main():
             strong_block = measure_strong(args, dto_amd, torch, dist, dev, rank, world, fence, n, m)
         except Exception as e:
             strong_block = {"error": repr(e)}
+
+    if watchdog is not None:
+        watchdog.cancel()
 
     # per-step times, each step fenced on its own: the median next to the mean that `value` is (SURVEY.md §8d quotes a median)
     step_ms = []
