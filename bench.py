@@ -337,6 +337,7 @@ def main():
     ap.add_argument("--callback", default="jacobian", choices=["jacobian", "hessian", "constraint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-callbacks", action="store_true")
+    ap.add_argument("--no-bound-output", action="store_true", help="skip the bound-output report block (profiling passes: every traced call is then a default call)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="leave the engine's HIP-event kernel timing off (measures its cost; the roofline block is then empty)")
     ap.add_argument("--serial-kernels", action="store_true",
@@ -553,7 +554,7 @@ def main():
     # device vector every iteration, can declare): the call-invariant half of the slab is then written once, not per call.
     # Reported next to `value`, never as `value` -- the headline keeps the reference's semantics (every entry written per call).
     bound_block = None
-    if args.callback in ("jacobian", "hessian") and world == 1:
+    if args.callback in ("jacobian", "hessian") and world == 1 and not args.no_bound_output:
         vec = dto_amd.capi.VECTOR_JACOBIAN if args.callback == "jacobian" else dto_amd.capi.VECTOR_HESSIAN
         ev.bind_output_dev(vec, out.data_ptr())
         for _ in range(max(2, args.warmup)):

@@ -10,8 +10,8 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # per-kernel figures need one kernel at a time: --serial-kernels (option overlap_sweep = 0); the default run is traced once too
-B="python3 $R/bench.py --no-cpu-baseline --no-other-callbacks --serial-kernels"
-BO="python3 $R/bench.py --no-cpu-baseline --no-other-callbacks --no-kernel-timing"
+B="python3 $R/bench.py --no-cpu-baseline --no-other-callbacks --no-bound-output --serial-kernels"
+BO="python3 $R/bench.py --no-cpu-baseline --no-other-callbacks --no-bound-output --no-kernel-timing"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- $B --steps 5 --warmup 2 > $O/prof_$tag.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_overlapped -- $BO --steps 5 --warmup 2 > $O/prof_${tag}_overlapped.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- $B --steps 2 --warmup 1 > $O/pmc_fetch_$tag.log 2>&1
