@@ -180,6 +180,35 @@ def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
                              "measured_in": "serial pass (overlap_sweep = 0), HIP events on the launch stream"}
         h["callback_hbm"] = {"algorithmic_bytes": nbytes, "achieved": nbytes / (h["ms_per_call"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": nbytes / (h["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # One interior-point iteration as Ipopt / MadNLP drive it: constraint, objective gradient, Jacobian and Hessian at a NEW
+        # point each time (nothing is carried from one point to the next), without and with option reuse_forward_sweep, under
+        # which the callbacks of one point share the forward sweep.  A report, never part of `value`.
+        ev.set_option("overlap_sweep", 1)
+        jac = torch.empty(ev.shard.jac_len, dtype=torch.float64, device=dev)
+        points = [Z + 1e-7 * (k + 1) for k in range(7)]
+        it = {}
+        for reuse in (0, 1):
+            ev.set_option("reuse_forward_sweep", reuse)
+
+            def iteration(Zk):
+                ev.eval_constraint_dev(Zk.data_ptr(), bufs["eval_constraint"].data_ptr(), stream)
+                ev.eval_gradient_dev(Zk.data_ptr(), bufs["eval_objective_gradient"].data_ptr(), stream)
+                ev.eval_jacobian_dev(Zk.data_ptr(), jac.data_ptr(), stream)
+                ev.eval_hessian_dev(Zk.data_ptr(), 1.0, mu.data_ptr(), bufs["eval_hessian_lagrangian"].data_ptr(), stream)
+
+            for Zk in points[:2]:
+                iteration(Zk)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for Zk in points[2:]:
+                iteration(Zk)
+            torch.cuda.synchronize(dev)
+            it[reuse] = (time.perf_counter() - t0) / len(points[2:]) * 1e3
+        ev.set_option("reuse_forward_sweep", 0)
+        out["solver_iteration"] = {"callbacks": "eval_constraint, eval_objective_gradient, eval_constraint_jacobian, eval_hessian_lagrangian "
+                                                "at a new point per iteration, device-resident vectors",
+                                   "ms_per_iteration": it[0], "ms_per_iteration_reuse_forward_sweep": it[1],
+                                   "finite": bool(torch.isfinite(jac).all().item() and torch.isfinite(bufs["eval_hessian_lagrangian"]).all().item())}
     finally:
         ev.close()
     return out

@@ -1183,9 +1183,15 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 if (same && b.cache_kind >= 2) return;  // the tangent sums of this very point are still in b.fw
                 SweepPlan plan = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);
                 SweepTypes ty = make_types(b.k.m, false);
-                if (same && b.p_terms && plan.q == 1) {
-                    // the p column of this very point is stored (eval_constraint or a Hessian came first): sweep the
-                    // tangent columns alone, their inhomogeneous terms read the stored p terms
+                // the p column of this very point is stored (eval_constraint or a Hessian came first)
+                const bool have_p = same && b.p_terms && plan.q == 1;
+                // ... but where the whole sweep runs as ONE persistent launch beside the chain, sweeping all columns again is
+                // cheaper than the step-per-launch form the frozen variant needs (256 x 2000: 10.9 against 12.0 ms per Jacobian);
+                // the stored p terms stay valid for a Hessian at this point either way (a sweep without store leaves them alone)
+                ClusterSweepPlan cp_unused;
+                const bool one_launch = fused_sweep_applies(h, b, b.fw, ty, plan, false) || cluster_sweep_applies(h, b, b.fw, ty, plan, false, cp_unused);
+                if (have_p && !one_launch) {
+                    // sweep the tangent columns alone, their inhomogeneous terms read the stored p terms
                     SweepBuf wf = b.fw;
                     wf.frozen = b.fw.Zt;
                     wf.frozen_total = b.p_steps + 1;
@@ -1196,7 +1202,8 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                     return;
                 }
                 // with reuse on and a Hessian to follow, keep every Taylor term so that the Hessian can skip its forward sweep
-                const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
+                // (not when the p terms are there already: they are all the Hessian's pairing takes from the forward sweep)
+                const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap && !have_p;
                 // (option "deterministic": the sweep keeps the shape it has when it runs alone, so the bits do not depend on
                 // overlap_sweep; next to the chain the 256-state sweep otherwise groups its intervals by twelve instead of nine)
                 const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep, false, false,

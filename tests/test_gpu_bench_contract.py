@@ -41,6 +41,8 @@ def test_single_gpu_line():
     assert "traffic_per_call" in rf
     hr = d["other_callbacks"]["eval_hessian_lagrangian"]
     assert hr["callback_hbm"]["algorithmic_bytes"] > 0
+    si = d["other_callbacks"]["solver_iteration"]   # g, grad f, J, H at a new point per iteration, without / with the shared forward sweep
+    assert si["finite"] is True and si["ms_per_iteration"] > 0 and si["ms_per_iteration_reuse_forward_sweep"] > 0, si
     if "roofline" in hr:   # (64 states x 1200 knots: the adjoint sweep runs in the fused or the cluster form, both timed)
         assert hr["roofline"]["bound"] == "mfma" and 0 < hr["roofline"]["frac"] < 1
 

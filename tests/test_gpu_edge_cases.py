@@ -328,6 +328,41 @@ def test_reuse_forward_sweep_between_callbacks():
         ref.close(); ev.close()
 
 
+@pytest.mark.parametrize("n,N", [(64, 900), (128, 700)])
+def test_reuse_forward_sweep_where_the_sweep_is_one_launch(n, N):
+    """The same option on shapes whose multi-column sweeps run as ONE persistent launch (fused / cluster form): a Jacobian that
+    finds the p terms of its point stored sweeps all columns again (cheaper than the frozen step-per-launch form) and leaves the
+    stored terms to the Hessian.  Compared with a handle that has the option off, every ordering, the point changing in between."""
+    import dto_amd
+    from helpers import rel_err
+    p = dto_amd.host.synthetic.make_scaled_problem(N, n, 2, seed=5)
+    ref = dto_amd.Evaluator(p)
+    ev = dto_amd.Evaluator(p)
+    ev.set_option("reuse_forward_sweep", 1)
+    rng = np.random.default_rng(1)
+    Z1 = p.trajectory.vec()
+    Z2 = Z1 + 0.02 * rng.standard_normal(Z1.size)
+    mu = rng.standard_normal(ref.n_constraints)
+
+    def one(e, what, Z):
+        if what == "g":
+            out = np.empty(e.n_constraints); e.eval_constraint(out, Z)
+        elif what == "J":
+            out = np.empty(e.n_jacobian_entries); e.eval_constraint_jacobian(out, Z)
+        else:
+            out = np.empty(e.n_hessian_entries); e.eval_hessian_lagrangian(out, Z, 0.9, mu)
+        return out
+
+    try:
+        want = {id(Z): {w: one(ref, w, Z) for w in ("g", "J", "H")} for Z in (Z1, Z2)}
+        for order in (("g", "J", "H"), ("J", "g", "H"), ("H", "J", "g"), ("g", "H", "J", "H")):
+            for Z in (Z1, Z2, Z1):
+                for what in order:
+                    assert rel_err(one(ev, what, Z), want[id(Z)][what]) <= 1e-12, (order, what)
+    finally:
+        ref.close(); ev.close()
+
+
 def test_host_pointer_hand_off_ships_only_what_changes():
     """dto_hostxfer: the host-pointer Jacobian / Hessian copy the variable runs only and fill constants on the host.  The
     result must be bit-identical to the whole-slab copy (option host_xfer = 0), into buffers pre-filled with garbage, for
