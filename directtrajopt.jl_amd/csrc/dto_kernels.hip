@@ -17,6 +17,7 @@
 //       every product with A = dt*sum_j ubar_j G_j is expanded over the SHARED generators, so that
 //       one step for all knots is a single GEMM  [G_0 .. G_m] x (columns of all knots)  (k_sweep).
 #include "dto_gemm.hip.h"
+#include "dto_gemm_ring.hip.h"
 #include "dto_kernels.h"
 #include "dto_hostxfer.h"
 
@@ -680,18 +681,90 @@ k_bgemm(BGemmArgs a) {
     }
 }
 
+// Epilogue of the paired-rows accumulator layout, shared by k_bgemm_p and the ring kernel k_bgemm_r: tile (tr, tc) of interval b.
+template <class Cfg, int EPI>
+__device__ __forceinline__ void bgemm_p_epilogue(const BGemmArgs& a, const GemmAccS<Cfg>& acc, int b, int tr, int tc, int s_b, int64_t nn) {
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, MP = Cfg::MT / 2;
+    GemmCoordP<Cfg> co;
+    const int row0 = tr * TM + co.row_base, col0 = tc * TN + co.col_base;
+    // -result into the Jacobian slab (x_k columns of the interval's own rows, evaluator.jl:514-525 /
+    // bilinear_integrator.jl:111-131): the last squaring, or the last polynomial product of an interval that needs none
+    const bool to_slab = (EPI == EPI_SQUARE && a.it == s_b - 1) || (EPI == EPI_HORNER && a.vals != nullptr && a.s[b] == 0);
+    double* Cb = a.C + b * nn;
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+    const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr, *M5 = nullptr;
+    double* Cb2 = nullptr;
+    if (epi_poly(EPI)) {
+        const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
+        c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
+        M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn; M4 = a.M4 + b * nn;
+        if (epi_dual(EPI)) {
+            const double* ef = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base2;
+            e0 = ef[0]; e1 = ef[1]; e2 = ef[2]; e3 = ef[3]; e4 = ef[4];
+            Cb2 = a.C2 + b * nn;
+            if (EPI == EPI_DUAL5) { M5 = a.M5 + b * nn; c5 = cf[5]; e5 = ef[5]; }
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < Cfg::NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = col0 + 16 * tj + 4 * r;
+            int64_t slab_base = 0;
+            if ((EPI == EPI_SQUARE || EPI == EPI_HORNER) && to_slab && col < a.Bi.n)
+                slab_base = jac_pos(a.P, a.P.colptr, a.int0 + b, a.Bi.x_off + col, a.Bi.pre, a.Bi.n, 1, 0);
+#pragma unroll
+            for (int p = 0; p < MP; ++p) {
+                const int row = row0 + 32 * p;  // even; the lane also holds row + 1
+                const int64_t off = (int64_t)col * a.npad + row;
+                d2 v2 = {acc.v[2 * p][tj][r], acc.v[2 * p + 1][tj][r]};
+                if (epi_poly(EPI)) {
+                    // the second product of the three-product form has no A^4 term (EXPM3_*[4] = 0); in the first product of
+                    // either form M4 is the launch's own A operand (L2-hot)
+                    const d2 m1 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M1[off])),
+                             m2 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M2[off])),
+                             m3 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M3[off]));
+                    const d2 m4 = EPI == EPI_DUAL5 ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(&M4[off]);
+                    if (epi_dual(EPI)) {
+                        d2 w2 = v2;
+                        if (EPI == EPI_DUAL5) {
+                            const d2 m5 = *reinterpret_cast<const d2*>(&M5[off]);  // this launch's A operand
+                            w2 += e5 * m5;
+                            v2 += c5 * m5;
+                        }
+                        w2 += e1 * m1 + e2 * m2 + e3 * m3 + e4 * m4;
+                        if (row == col) w2.x += e0;
+                        if (row + 1 == col) w2.y += e0;
+                        __builtin_nontemporal_store(w2, reinterpret_cast<d2*>(&Cb2[off]));
+                    }
+                    v2 += c1 * m1 + c2 * m2 + c3 * m3 + c4 * m4;  // streamed once per stage
+                    if (row == col) v2.x += c0;
+                    if (row + 1 == col) v2.y += c0;
+                }
+                if ((EPI == EPI_SQUARE || EPI == EPI_HORNER) && to_slab) {
+                    if (col < a.Bi.n) {  // slab columns are only 8-byte aligned; never re-read by the engine
+                        if (row + 1 < a.Bi.n) __builtin_nontemporal_store(d2u{-v2.x, -v2.y}, reinterpret_cast<d2u*>(&a.vals[slab_base + row]));
+                        else if (row < a.Bi.n) __builtin_nontemporal_store(-v2.x, &a.vals[slab_base + row]);
+                    }
+                    continue;
+                }
+                __builtin_nontemporal_store(v2, reinterpret_cast<d2*>(&Cb[off]));  // 1 GB per launch: gone from L2 before its reader starts
+            }
+            if (epi_dual(EPI)) __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later columns from piling up (spills)
+        }
+}
+
 // The same batched product on the paired-rows core (dto_gemm.hip.h, round 3): 16-byte fragment reads, A panels by LDS-DMA
 // (DMA_A) or through registers, every epilogue access 16 bytes per lane.  Epilogue semantics are those of k_bgemm.
 template <class Cfg, int EPI, bool DMA_A>
 __global__ void __launch_bounds__(Cfg::THREADS, (Cfg::THREADS / 256) * 2)
 k_bgemm_p(BGemmArgs a) {
     __shared__ __attribute__((aligned(1024))) double smem[Cfg::SMEM_DOUBLES];
-    constexpr int TM = Cfg::TM, TN = Cfg::TN, MP = Cfg::MT / 2;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
     const int tiles_r = a.npad / TM;
     const int tpm = tiles_r * (a.npad / TN);
     const int total = batch_tile_count(a.nbatch, tpm);
     const int64_t nn = (int64_t)a.npad * a.npad;
-    GemmCoordP<Cfg> co;
     for (int v = blockIdx.x; v < total; v += gridDim.x) {
         int b, tile;
         if (!decode_batch_tile(v, a.nbatch, tpm, b, tile)) continue;
@@ -733,73 +806,40 @@ k_bgemm_p(BGemmArgs a) {
         } stamp_at_exit{a.stamps ? a.stamps + 8ll * v : nullptr, st0, st1, rt0, waits[0], waits[1]};
 #endif
 
-        const int row0 = tr * TM + co.row_base, col0 = tc * TN + co.col_base;
-        // -result into the Jacobian slab (x_k columns of the interval's own rows, evaluator.jl:514-525 /
-        // bilinear_integrator.jl:111-131): the last squaring, or the last polynomial product of an interval that needs none
-        const bool to_slab = (EPI == EPI_SQUARE && a.it == s_b - 1) || (EPI == EPI_HORNER && a.vals != nullptr && a.s[b] == 0);
-        double* Cb = a.C + b * nn;
-        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
-        const double *M1 = nullptr, *M2 = nullptr, *M3 = nullptr, *M4 = nullptr, *M5 = nullptr;
-        double* Cb2 = nullptr;
-        if (epi_poly(EPI)) {
-            const double* cf = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base;
-            c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
-            M1 = a.M1 + b * nn; M2 = a.M2 + b * nn; M3 = a.M3 + b * nn; M4 = a.M4 + b * nn;
-            if (epi_dual(EPI)) {
-                const double* ef = a.coef + (int64_t)b * COEF_STRIDE + a.coef_base2;
-                e0 = ef[0]; e1 = ef[1]; e2 = ef[2]; e3 = ef[3]; e4 = ef[4];
-                Cb2 = a.C2 + b * nn;
-                if (EPI == EPI_DUAL5) { M5 = a.M5 + b * nn; c5 = cf[5]; e5 = ef[5]; }
-            }
-        }
-#pragma unroll
-        for (int tj = 0; tj < Cfg::NT; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = col0 + 16 * tj + 4 * r;
-                int64_t slab_base = 0;
-                if ((EPI == EPI_SQUARE || EPI == EPI_HORNER) && to_slab && col < a.Bi.n)
-                    slab_base = jac_pos(a.P, a.P.colptr, a.int0 + b, a.Bi.x_off + col, a.Bi.pre, a.Bi.n, 1, 0);
-#pragma unroll
-                for (int p = 0; p < MP; ++p) {
-                    const int row = row0 + 32 * p;  // even; the lane also holds row + 1
-                    const int64_t off = (int64_t)col * a.npad + row;
-                    d2 v2 = {acc.v[2 * p][tj][r], acc.v[2 * p + 1][tj][r]};
-                    if (epi_poly(EPI)) {
-                        // the second product of the three-product form has no A^4 term (EXPM3_*[4] = 0); in the first product of
-                        // either form M4 is the launch's own A operand (L2-hot)
-                        const d2 m1 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M1[off])),
-                                 m2 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M2[off])),
-                                 m3 = __builtin_nontemporal_load(reinterpret_cast<const d2*>(&M3[off]));
-                        const d2 m4 = EPI == EPI_DUAL5 ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(&M4[off]);
-                        if (epi_dual(EPI)) {
-                            d2 w2 = v2;
-                            if (EPI == EPI_DUAL5) {
-                                const d2 m5 = *reinterpret_cast<const d2*>(&M5[off]);  // this launch's A operand
-                                w2 += e5 * m5;
-                                v2 += c5 * m5;
-                            }
-                            w2 += e1 * m1 + e2 * m2 + e3 * m3 + e4 * m4;
-                            if (row == col) w2.x += e0;
-                            if (row + 1 == col) w2.y += e0;
-                            __builtin_nontemporal_store(w2, reinterpret_cast<d2*>(&Cb2[off]));
-                        }
-                        v2 += c1 * m1 + c2 * m2 + c3 * m3 + c4 * m4;  // streamed once per stage
-                        if (row == col) v2.x += c0;
-                        if (row + 1 == col) v2.y += c0;
-                    }
-                    if ((EPI == EPI_SQUARE || EPI == EPI_HORNER) && to_slab) {
-                        if (col < a.Bi.n) {  // slab columns are only 8-byte aligned; never re-read by the engine
-                            if (row + 1 < a.Bi.n) __builtin_nontemporal_store(d2u{-v2.x, -v2.y}, reinterpret_cast<d2u*>(&a.vals[slab_base + row]));
-                            else if (row < a.Bi.n) __builtin_nontemporal_store(-v2.x, &a.vals[slab_base + row]);
-                        }
-                        continue;
-                    }
-                    __builtin_nontemporal_store(v2, reinterpret_cast<d2*>(&Cb[off]));  // 1 GB per launch: gone from L2 before its reader starts
-                }
-                if (epi_dual(EPI)) __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later columns from piling up (spills)
-            }
+        bgemm_p_epilogue<Cfg, EPI>(a, acc, b, tr, tc, s_b, nn);
     }
+}
+
+// The same products on the ring core (dto_gemm_ring.hip.h): persistent, K panels of all of a workgroup's tiles in one LDS ring.
+template <int EPI, int S>
+__global__ void __launch_bounds__(512, 4) k_bgemm_r(BGemmArgs a) {
+    using R = RingCore<8, S>;
+    using Cfg = typename R::Cfg;
+    __shared__ __attribute__((aligned(1024))) double smem[R::SMEM_DOUBLES];
+    const int tiles_r = a.npad / 128;
+    const int tpm = tiles_r * tiles_r;
+    const int total = batch_tile_count(a.nbatch, tpm);
+    const int64_t nn = (int64_t)a.npad * a.npad;
+    R::run(smem, (int)blockIdx.x, (int)gridDim.x,
+           [&](int& pos, RingTile& t) {
+               int b = 0, tile = 0;
+               for (; pos < total; pos += (int)gridDim.x) {
+                   if (!decode_batch_tile(pos, a.nbatch, tpm, b, tile)) continue;
+                   if (EPI == EPI_SQUARE && a.it >= a.s[b]) continue;  // this interval needs no further squaring
+                   break;
+               }
+               if (pos >= total) return false;
+               const int tr = tile % tiles_r, tc = tile / tiles_r;
+               t.A = a.A + b * nn + (int64_t)tr * 128; t.lda = a.npad;
+               t.B = a.B + b * nn + (int64_t)tc * 128 * a.npad; t.ldb = a.npad;
+               t.nk = a.npad / 8;
+               return true;
+           },
+           [&](int pos, const GemmAccS<Cfg>& acc) {
+               int b = 0, tile = 0;
+               decode_batch_tile(pos, a.nbatch, tpm, b, tile);
+               bgemm_p_epilogue<Cfg, EPI>(a, acc, b, tile % tiles_r, tile / tiles_r, EPI == EPI_SQUARE ? a.s[b] : 0, nn);
+           });
 }
 
 static int bgemm_shape_choice() {
@@ -893,6 +933,18 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
     const bool small_launch = force64 >= 0 ? force64 != 0 : t128 * t128 * t128 * a.nbatch < 3500;
     if (a.npad % 128 == 0 && small_launch && bgemm_shape_choice() < 0) {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
+        return;
+    }
+    // Ring core (persistent, K panels of all tiles in one LDS ring, both operands by LDS-DMA) for the plain products and the
+    // squarings: 1.47 -> 1.39 ms per squaring at 256 x 2000, 2.28 -> 2.01 ms at 512 x 500, 8.16 -> 7.65 ms at 1024 x 500.  The
+    // polynomial products stay one workgroup per tile on the double-buffered core: they are bound by the bytes of their epilogues
+    // (1.63 against 1.87 ms at 256 states, 2.46 against 2.61 at 512, 8.6 against 9.05 at 1024: gpurun_out/r03ah/ab_ring*.log)
+    static const int ring = tune_int("DTO_BGEMM_RING", -1);  // -1: as described, 0: never, 1: always
+    const bool use_ring = ring >= 0 ? ring != 0 : !epi_poly(EPI);
+    if (a.npad % 128 == 0 && use_ring && bgemm_shape_choice() < 0) {
+        int grid = batch_tile_count(a.nbatch, (a.npad / 128) * (a.npad / 128));
+        if (grid > 2 * 256) grid = 2 * 256;
+        hipLaunchKernelGGL((k_bgemm_r<EPI, 4>), dim3(grid), dim3(512), 0, st, a);
         return;
     }
     static const int core = tune_int("DTO_BGEMM_CORE", 1);  // 1: paired-rows core (round 3), 0: the 8-byte core

@@ -11,7 +11,7 @@
 //   * the DMA pieces of panel q+S-1 are issued between the MFMAs as well; the only thing a wave does outside the MFMA stream is
 //     s_waitcnt vmcnt(P) + s_barrier;
 //   * persistent grid, and the ring runs on across tiles: the first panels of the next tile are in flight during the epilogue.
-// usage: bgemm_probe5 [nbatch=2000] [reps=10] [square=0|1]
+// usage: bgemm_probe5 [nbatch=2000] [reps=10] [square=0|1] [unused] [npad=256]
 #define main probe4_main
 #include "bgemm_probe4.hip"
 #undef main
@@ -201,7 +201,7 @@ void check(const char* name, K k, int threads, const double* A, const double* Bm
 }
 
 int main(int argc, char** argv) {
-    const int npad = 256, nb = argc > 1 ? atoi(argv[1]) : 2000;
+    const int npad = argc > 5 ? atoi(argv[5]) : 256, nb = argc > 1 ? atoi(argv[1]) : 2000;
     const int reps = argc > 2 ? atoi(argv[2]) : 10;
     const int square = argc > 3 ? atoi(argv[3]) : 0;
     const size_t nn = (size_t)npad * npad;
