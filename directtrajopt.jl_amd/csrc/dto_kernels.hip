@@ -935,15 +935,16 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
         return;
     }
-    // Ring core (persistent, K panels of all tiles in one LDS ring, both operands by LDS-DMA) for the plain products and the
-    // squarings: 1.47 -> 1.39 ms per squaring at 256 x 2000, 2.28 -> 2.01 ms at 512 x 500, 8.16 -> 7.65 ms at 1024 x 500.  The
-    // polynomial products stay one workgroup per tile on the double-buffered core: they are bound by the bytes of their epilogues
-    // (1.63 against 1.87 ms at 256 states, 2.46 against 2.61 at 512, 8.6 against 9.05 at 1024: gpurun_out/r03ah/ab_ring*.log)
-    static const int ring = tune_int("DTO_BGEMM_RING", -1);  // -1: as described, 0: never, 1: always
-    const bool use_ring = ring >= 0 ? ring != 0 : !epi_poly(EPI);
-    if (a.npad % 128 == 0 && use_ring && bgemm_shape_choice() < 0) {
+    // Ring core (K panels in an LDS ring, both operands by LDS-DMA, dto_gemm_ring.hip.h).  The plain products and the squarings run
+    // it PERSISTENT (the next tile's panels in flight during the epilogue): 1.47 -> 1.39 ms per squaring at 256 x 2000, 2.28 -> 2.01
+    // at 512 x 500, 8.16 -> 7.65 at 1024 x 500.  The polynomial products, bound by the bytes of their epilogues, keep one workgroup per
+    // tile (persistent they lose 5-15 %) and still gain from the ring inside the tile: 1.60 -> 1.535 ms at 256 x 2000, 8.63 -> 8.29 at
+    // 1024 x 500 (gpurun_out/r03ah/ab_ring*.log).
+    static const int ring = tune_int("DTO_BGEMM_RING", -1);  // -1: as described, 0: never, 1: everything persistent
+    if (a.npad % 128 == 0 && ring != 0 && bgemm_shape_choice() < 0) {
         int grid = batch_tile_count(a.nbatch, (a.npad / 128) * (a.npad / 128));
-        if (grid > 2 * 256) grid = 2 * 256;
+        if (grid > 2 * 256 && (ring == 1 || !epi_poly(EPI))) grid = 2 * 256;
+        // (three or five slots, two or four tiles per workgroup for the polynomial products: all slower, gpurun_out/r03ah/ab_ring5.log)
         hipLaunchKernelGGL((k_bgemm_r<EPI, 4>), dim3(grid), dim3(512), 0, st, a);
         return;
     }
