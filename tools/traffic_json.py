@@ -7,6 +7,7 @@ streaming reads; WRITE_SIZE as read; both counters are in KB), the k_bgemm famil
 import collections
 import csv
 import json
+import re
 import sys
 
 
@@ -40,7 +41,8 @@ def main():
            "algorithmic_per_call_bytes": 8.0 * (275462200 + 530000 + 5 * 256 * 256)}
     i = 0
     for k, v in bg.items():
-        epi = k.split(">, ")[1].split(",")[0] if ">, " in k else "?"
+        m = re.search(r"k_bgemm_r<(\d+),", k) or re.search(r">, (\d+),", k)   # epilogue kind: ring kernel / double-buffered kernels
+        epi = m.group(1) if m else "?"
         name = "square" if epi == "2" else f"product{ {'3': 1, '4': 2, '1': 3}.get(epi, 9) }"
         out["per_launch_bytes"][name] = {"read": v["read"], "write": v["write"], "kernel": k[:100]}
     pl = out["per_launch_bytes"]
