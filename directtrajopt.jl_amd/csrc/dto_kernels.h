@@ -232,6 +232,7 @@ void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const d
 struct FusedSweepPlan {
     int MT, NT, ipw, nslot, nblocks;
     int WC = 1;  // column groups of wavefronts (4 WC wavefronts per workgroup), NT column tiles per group
+    int WK = 1;  // 2: two wavefronts per SIMD split the K loop of a wave tile (256 states)
     size_t lds_bytes;
 };
 hipError_t sweep_fused_prepare();  // per-device opt-in to the kernels' dynamic LDS (dto_create)

@@ -57,7 +57,7 @@ struct FusedLds {
         const int NC = T * ipw, ZS = npad + 2;
         (void)nslot; (void)MT;
         int o = 0;
-        zs = o; o += NC * ZS + 4;  // + 4: the B-fragment prefetch runs one k-step past the last column
+        zs = o; o += NC * ZS + 40; // the B-fragment prefetch runs up to two groups of four k-steps past the last column (K split)
         scr = o;
         cg = o; o += (m + 1) * ipw;
         se = o; o += ipw;
@@ -77,13 +77,21 @@ struct FusedLds {
 // at the end.
 // WC column groups of wavefronts: wavefront (wr, wc) owns rows 16 MT wr .. and the column tiles NT wc .. NT (wc + 1) - 1; WC = 2
 // puts two wavefronts on every SIMD, each with the k-loop of a two-tile workgroup.
-template <int MT, int NT, int WC>
-__global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) {
-    constexpr int NTHREADS = 256 * WC, NWAVES = 4 * WC;
+// WK = 2 (256 states): TWO wavefronts per SIMD share a wave tile and split its K loop -- groups of PF k-steps alternate between
+// them, each wave with its own accumulators; at the end of a term each wave hands the OTHER wave the partial sums of the row pair
+// that wave owns (through the LDS term columns, which are being replaced anyway) and finishes its own pair: sums, norms, the new
+// term.  One wave per SIMD cannot keep the matrix pipe busy through its own LDS and L2 latencies (MFMA utilisation 0.64); two
+// that depend on nothing of each other's can.  The per-MFMA scaling arithmetic and the generator stream are NOT duplicated (the
+// k-steps are disjoint), which is what the row- and column-split two-wave forms paid for.
+template <int MT, int NT, int WC, int WK = 1>
+__global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSweepArgs a) {
+    static_assert(WK == 1 || (WK == 2 && MT == 4 && WC == 1), "the K split is built for 256 states");
+    constexpr int NTHREADS = 256 * WC * WK, NWAVES = 4 * WC * WK;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RL = 16 * MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    const int wr = wave & 3, ct0 = (wave >> 2) * NT;  // row group, first column tile
+    const int wr = wave & 3, ct0 = ((wave >> 2) % WC) * NT;  // row group, first column tile
+    const int wk = (wave >> 2) / WC;                           // K half (WK = 2)
     const int npad = a.w.npad, Kpad = a.w.Kpad, T = a.ty.T, m = a.B.m, ipw = a.ipw;
     const int NC = T * ipw, ZS = npad + 2, KS = npad / 4;
     const int64_t typesz = (int64_t)Kpad * npad, nn = (int64_t)npad * npad;
@@ -181,16 +189,19 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
     // sums of this lane's accumulator elements: element (ti, tj, r) is row rowbase + 32 (ti/2) + 2 lr + (ti & 1) [MT >= 2] of
     // column 16 tj + 4 r + lq
     const int rowbase = wr * RL;
-    d4 sreg[MT][NT];
+    // WK = 2: a wave keeps the sums of ONE row pair (tiles 2 wk, 2 wk + 1 -> sreg[0], sreg[1]); own_row = first row of that pair
+    constexpr int SR = WK == 2 ? 2 : MT;
+    d4 sreg[SR][NT];
+    const int own_row = rowbase + 32 * wk + 2 * lr;
     auto lane_row = [&](int ti) { return MT >= 2 ? rowbase + 32 * (ti / 2) + 2 * lr + (ti & 1) : rowbase + lr; };
 #pragma unroll
-    for (int ti = 0; ti < MT; ++ti)
+    for (int ti = 0; ti < SR; ++ti)
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * (ct0 + tj) + 4 * r + lq;
-                sreg[ti][tj][r] = c < NC ? Zs[c * ZS + lane_row(ti)] : 0.0;
+                sreg[ti][tj][r] = c < NC ? Zs[c * ZS + (WK == 2 ? own_row + ti : lane_row(ti))] : 0.0;
             }
 
     int t_exit = 0;
@@ -199,13 +210,13 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
         if (round > 0) {
             // next sub-interval of exp(A) = exp(A/q)^q: the sums become term 0 of the new series
 #pragma unroll
-            for (int ti = 0; ti < MT; ++ti)
+            for (int ti = 0; ti < SR; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = 16 * (ct0 + tj) + 4 * r + lq;
-                        if (c < NC) Zs[c * ZS + lane_row(ti)] = sreg[ti][tj][r];
+                        if (c < NC) Zs[c * ZS + (WK == 2 ? own_row + ti : lane_row(ti))] = sreg[ti][tj][r];
                     }
             __syncthreads();
             for (int c = wave; c < NC; c += NWAVES) {
@@ -237,7 +248,10 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
                     for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = d4{0.0, 0.0, 0.0, 0.0};
                 constexpr int AP = MT >= 2 ? MT / 2 : 1;
                 d2 abuf[PF][AP];
-                const double* abase = a.G + ((int64_t)g_first * KS + ks_first) * astep;
+                // (WK = 2: this wave's groups of PF k-steps are every other one of the stream, starting with group wk)
+                const double* abase = a.G + ((int64_t)g_first * KS + ks_first + (WK == 2 ? wk * PF : 0)) * astep;
+                if (WK == 2 && abase >= aend) abase -= (int64_t)(m + 1) * nn;
+                int in_group = 0;
                 auto issue = [&](int slot) {
                     const double* p = abase + aoff;
 #pragma unroll
@@ -246,7 +260,12 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
                         else abuf[slot][q2] = d2{p[0], 0.0};
                     }
                     abase += astep;
-                    if (abase == aend) abase = a.G;
+                    if constexpr (WK == 2) {
+                        if (++in_group == PF) { in_group = 0; abase += PF * astep; }   // the other wave's group
+                        if (abase >= aend) abase -= (int64_t)(m + 1) * nn;
+                    } else {
+                        if (abase == aend) abase = a.G;
+                    }
                 };
 #pragma unroll
                 for (int u = 0; u < PF; ++u) issue(u);
@@ -275,12 +294,13 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
                                 cB[tj] = sE[bin[tj]] * xm[2 * bty[tj] + x];
                                 so = (xs[2 * bty[tj] + x] * ipw + bin[tj]) * ZS + lq;
                             }
-                        zp1[tj] = Zs + bcol[tj] + 4 * ks_lo;
-                        zp2[tj] = Zs + so + 4 * ks_lo;
+                        zp1[tj] = Zs + bcol[tj] + 4 * (ks_lo + (WK == 2 ? wk * PF : 0));
+                        zp2[tj] = Zs + so + 4 * (ks_lo + (WK == 2 ? wk * PF : 0));
                         z1[tj] = zp1[tj][0];
                         z2[tj] = zp2[tj][0];
                     }
-                    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += PF) {
+                    // (every segment holds an even number of groups: KS / PF and ks_first / PF are multiples of four)
+                    for (int ks0 = ks_lo + (WK == 2 ? wk * PF : 0); ks0 < ks_hi; ks0 += PF * WK) {
 #pragma unroll
                         for (int u = 0; u < PF; ++u) {
                             double bf[NT];
@@ -297,8 +317,8 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
 #ifndef PROBE_NO_BLOAD
 #pragma unroll
                             for (int tj = 0; tj < NT; ++tj) {
-                                z1[tj] = zp1[tj][4 * (u + 1)];
-                                z2[tj] = zp2[tj][4 * (u + 1)];
+                                z1[tj] = zp1[tj][4 * (u + 1 == PF ? PF * WK : u + 1)];   // (the wave's next group)
+                                z2[tj] = zp2[tj][4 * (u + 1 == PF ? PF * WK : u + 1)];
                             }
 #endif
                             __builtin_amdgcn_sched_barrier(0);  // the reads go out BEFORE the MFMA block, which hides them
@@ -317,59 +337,116 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
 #endif
                         }
 #pragma unroll
-                        for (int tj = 0; tj < NT; ++tj) { zp1[tj] += 4 * PF; zp2[tj] += 4 * PF; }
+                        for (int tj = 0; tj < NT; ++tj) { zp1[tj] += 4 * PF * WK; zp2[tj] += 4 * PF * WK; }
                     }
                 }
-                // ---- new term of this row pass: sums, column norms, stores.  Accumulator register r of column tile tj
-                // holds column 16 tj + 4 r + lq
+                if constexpr (WK == 2) {
+                    // ---- K split: hand the other wave of the SIMD the partial sums of ITS row pair, finish the own pair
+                    __syncthreads();  // every wave is done with the old term columns
+                    auto finish = [&](auto own_c) {
+                        constexpr int OWN = decltype(own_c)::value, OTHER = 1 - OWN;
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
+                        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * (ct0 + tj) + 4 * r + lq;
-                        const int cc = c < NC ? c : 0;
-                        const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
-                        const bool ok = c < NC && kl < Kpad;
-                        const int64_t colbase = ((int64_t)ty * Kpad + kl) * npad + rowbase;
-                        double tmax = 0.0, smax = 0.0;
-                        bool bad_t = false, bad_s = false;
-                        if (ok) {
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                                if (c < NC)
+                                    *reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * OTHER + 2 * lr) =
+                                        d2{acc[2 * OTHER][tj][r], acc[2 * OTHER + 1][tj][r]};
+                            }
+                        __syncthreads();
 #pragma unroll
-                            for (int p = 0; p < (MT >= 2 ? MT / 2 : 1); ++p) {
-                                const int64_t off = colbase + (MT >= 2 ? 32 * p + 2 * lr : lr);
-                                d2 v, sv;
-                                if constexpr (MT >= 2) v = d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
-                                else v = d2{acc[0][tj][r] * inv, 0.0};
-                                if constexpr (MT >= 2) {
-                                    sv = d2{sreg[2 * p][tj][r] + v.x, sreg[2 * p + 1][tj][r] + v.y};
-                                    sreg[2 * p][tj][r] = sv.x; sreg[2 * p + 1][tj][r] = sv.y;
-                                } else {
-                                    sv = d2{sreg[0][tj][r] + v.x, 0.0};
-                                    sreg[0][tj][r] = sv.x;
+                        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                                const int cc = c < NC ? c : 0;
+                                const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
+                                const bool ok = c < NC && kl < Kpad;
+                                double tmax = 0.0, smax = 0.0;
+                                bool bad_t = false, bad_s = false;
+                                if (c < NC) {
+                                    d2* zpos = reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * OWN + 2 * lr);
+                                    const d2 part = *zpos;   // the other wave's k-steps
+                                    const d2 v = d2{(acc[2 * OWN][tj][r] + part.x) * inv, (acc[2 * OWN + 1][tj][r] + part.y) * inv};
+                                    *zpos = v;               // the new term becomes the B operand of the next step
+                                    if (ok) {
+                                        const d2 sv = d2{sreg[0][tj][r] + v.x, sreg[1][tj][r] + v.y};
+                                        sreg[0][tj][r] = sv.x; sreg[1][tj][r] = sv.y;
+                                        if (a.store) *reinterpret_cast<d2*>(Zout + ((int64_t)ty * Kpad + kl) * npad + rowbase + 32 * OWN + 2 * lr) = v;
+                                        tmax = fmax(fabs(v.x), fabs(v.y));
+                                        smax = fmax(fabs(sv.x), fabs(sv.y));
+                                        bad_t = !(v.x == v.x) || !(v.y == v.y);      // NaN must survive the max
+                                        bad_s = !(sv.x == sv.x) || !(sv.y == sv.y);
+                                    }
                                 }
-                                if (a.store) {
-                                    if constexpr (MT >= 2) *reinterpret_cast<d2*>(Zout + off) = v;
-                                    else Zout[off] = v.x;
+                                unsigned long long tb = bad_t ? 0x7ff8000000000000ull : fbits(tmax), sb = bad_s ? 0x7ff8000000000000ull : fbits(smax);
+#pragma unroll
+                                for (int o = 8; o > 0; o >>= 1) {
+                                    const unsigned long long t2 = __shfl_xor(tb, o, 64), s2 = __shfl_xor(sb, o, 64);
+                                    tb = t2 > tb ? t2 : tb;
+                                    sb = s2 > sb ? s2 : sb;
                                 }
-                                tmax = fmax(tmax, fmax(fabs(v.x), fabs(v.y)));
-                                smax = fmax(smax, fmax(fabs(sv.x), fabs(sv.y)));
-                                bad_t = bad_t || !(v.x == v.x) || !(v.y == v.y);      // NaN must survive the max
-                                bad_s = bad_s || !(sv.x == sv.x) || !(sv.y == sv.y);
+                                if (ok && lr == 0) {
+                                    atomicMax(&tn_new[c], tb);
+                                    atomicMax(&sn[c], sb);
+                                }
+                            }
+                    };
+                    if (wk == 0) finish(std::integral_constant<int, 0>{});
+                    else finish(std::integral_constant<int, 1>{});
+                } else {
+                    // ---- new term of this row pass: sums, column norms, stores.  Accumulator register r of column tile tj
+                    // holds column 16 tj + 4 r + lq
+    #pragma unroll
+                    for (int tj = 0; tj < NT; ++tj)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                            const int cc = c < NC ? c : 0;
+                            const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
+                            const bool ok = c < NC && kl < Kpad;
+                            const int64_t colbase = ((int64_t)ty * Kpad + kl) * npad + rowbase;
+                            double tmax = 0.0, smax = 0.0;
+                            bool bad_t = false, bad_s = false;
+                            if (ok) {
+    #pragma unroll
+                                for (int p = 0; p < (MT >= 2 ? MT / 2 : 1); ++p) {
+                                    const int64_t off = colbase + (MT >= 2 ? 32 * p + 2 * lr : lr);
+                                    d2 v, sv;
+                                    if constexpr (MT >= 2) v = d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
+                                    else v = d2{acc[0][tj][r] * inv, 0.0};
+                                    if constexpr (MT >= 2) {
+                                        sv = d2{sreg[2 * p][tj][r] + v.x, sreg[2 * p + 1][tj][r] + v.y};
+                                        sreg[2 * p][tj][r] = sv.x; sreg[2 * p + 1][tj][r] = sv.y;
+                                    } else {
+                                        sv = d2{sreg[0][tj][r] + v.x, 0.0};
+                                        sreg[0][tj][r] = sv.x;
+                                    }
+                                    if (a.store) {
+                                        if constexpr (MT >= 2) *reinterpret_cast<d2*>(Zout + off) = v;
+                                        else Zout[off] = v.x;
+                                    }
+                                    tmax = fmax(tmax, fmax(fabs(v.x), fabs(v.y)));
+                                    smax = fmax(smax, fmax(fabs(sv.x), fabs(sv.y)));
+                                    bad_t = bad_t || !(v.x == v.x) || !(v.y == v.y);      // NaN must survive the max
+                                    bad_s = bad_s || !(sv.x == sv.x) || !(sv.y == sv.y);
+                                }
+                            }
+                            // compare bit patterns: a NaN's exceeds every finite one
+                            unsigned long long tb = bad_t ? 0x7ff8000000000000ull : fbits(tmax), sb = bad_s ? 0x7ff8000000000000ull : fbits(smax);
+    #pragma unroll
+                            for (int o = 8; o > 0; o >>= 1) {
+                                const unsigned long long t2 = __shfl_xor(tb, o, 64), s2 = __shfl_xor(sb, o, 64);
+                                tb = t2 > tb ? t2 : tb;
+                                sb = s2 > sb ? s2 : sb;
+                            }
+                            if (ok && lr == 0) {
+                                atomicMax(&tn_new[c], tb);
+                                atomicMax(&sn[c], sb);
                             }
                         }
-                        // compare bit patterns: a NaN's exceeds every finite one
-                        unsigned long long tb = bad_t ? 0x7ff8000000000000ull : fbits(tmax), sb = bad_s ? 0x7ff8000000000000ull : fbits(smax);
-#pragma unroll
-                        for (int o = 8; o > 0; o >>= 1) {
-                            const unsigned long long t2 = __shfl_xor(tb, o, 64), s2 = __shfl_xor(sb, o, 64);
-                            tb = t2 > tb ? t2 : tb;
-                            sb = s2 > sb ? s2 : sb;
-                        }
-                        if (ok && lr == 0) {
-                            atomicMax(&tn_new[c], tb);
-                            atomicMax(&sn[c], sb);
-                        }
-                    }
+                            }
             }
             __syncthreads();  // every wave is done with the old term columns
             // Al-Mohy & Higham's test (as k_sweep_check): two successive terms below tol * |sum| in every column
@@ -383,23 +460,25 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
             }
             for (int c = tid; c < NC; c += NTHREADS) tn[((t + 2) % 3) * NC + c] = 0ull;
             if (tid == 0) flag[(t + 1) & 1] = 0;
-            // the new term becomes the B operand of the next step
-#pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * (ct0 + tj) + 4 * r + lq;
-                    if (c < NC) {
-                        if constexpr (MT >= 2) {
-#pragma unroll
-                            for (int p = 0; p < MT / 2; ++p)
-                                *reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * p + 2 * lr) =
-                                    d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
-                        } else {
-                            Zs[c * ZS + rowbase + lr] = acc[0][tj][r] * inv;
+            if constexpr (WK == 1) {
+                // the new term becomes the B operand of the next step
+    #pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                        if (c < NC) {
+                            if constexpr (MT >= 2) {
+    #pragma unroll
+                                for (int p = 0; p < MT / 2; ++p)
+                                    *reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * p + 2 * lr) =
+                                        d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
+                            } else {
+                                Zs[c * ZS + rowbase + lr] = acc[0][tj][r] * inv;
+                            }
                         }
                     }
-                }
+            }
             __syncthreads();
             if (flag[t & 1] == 0) { conv = true; break; }
         }
@@ -417,7 +496,9 @@ __global__ void __launch_bounds__(256 * WC, WC) k_sweep_fused(FusedSweepArgs a) 
                 const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
                 if (c < NC && kl < Kpad) {
                     const int64_t colbase = ((int64_t)ty * Kpad + kl) * npad + rowbase;
-                    if constexpr (MT >= 2) {
+                    if constexpr (WK == 2) {
+                        *reinterpret_cast<d2*>(a.w.S + colbase + 32 * wk + 2 * lr) = d2{sreg[0][tj][r], sreg[1][tj][r]};
+                    } else if constexpr (MT >= 2) {
 #pragma unroll
                         for (int p = 0; p < MT / 2; ++p)
                             *reinterpret_cast<d2*>(a.w.S + colbase + 32 * p + 2 * lr) = d2{sreg[2 * p][tj][r], sreg[2 * p + 1][tj][r]};
@@ -913,15 +994,15 @@ __global__ void __launch_bounds__(256, 1) k_sweep_cluster(ClusterArgs ca) {
     }
 }
 
-template <int MT, int NT, int WC = 1>
+template <int MT, int NT, int WC = 1, int WK = 1>
 hipError_t launch_one(hipStream_t st, const FusedSweepArgs& a, int nblocks, size_t lds) {
     if (a.w.npad != 64 * MT) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_sweep_fused<MT, NT, WC>), dim3(nblocks), dim3(256 * WC), lds, st, a);
+    hipLaunchKernelGGL((k_sweep_fused<MT, NT, WC, WK>), dim3(nblocks), dim3(256 * WC * WK), lds, st, a);
     return hipGetLastError();
 }
-template <int MT, int NT, int WC = 1>
+template <int MT, int NT, int WC = 1, int WK = 1>
 hipError_t prepare_one(int bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<MT, NT, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_fused<MT, NT, WC, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace
@@ -935,6 +1016,9 @@ hipError_t sweep_fused_prepare() {
     DTO_PREP(1, 1); DTO_PREP(1, 2); DTO_PREP(1, 3);
 #undef DTO_PREP
     if (e == hipSuccess) e = prepare_one<4, 2, 2>(bytes);
+    if (e == hipSuccess) e = prepare_one<4, 1, 1, 2>(bytes);
+    if (e == hipSuccess) e = prepare_one<4, 2, 1, 2>(bytes);
+    if (e == hipSuccess) e = prepare_one<4, 3, 1, 2>(bytes);
     return e;
 }
 
@@ -997,8 +1081,12 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
     // wavefronts per SIMD hide each other's operand traffic, +10 % MFMA rate per CU -- but a third fewer workgroups, each a
     // fifth longer (256 x 2000: 167 workgroups, 4.0 ms against 223, 3.3 ms).  It pays when the CUs the sweep leaves free are
     // used by another stream (`shared_chip`: the Jacobian's sweep next to the propagator chain), not when the sweep runs alone.
+    static const int wk_env = tune_int("DTO_SWEEP_WK", 2);  // A/B runs (TUNING builds): 1 = one wave per SIMD as up to round 3
+    out.WK = 1;
     if (shared_chip && npad == 256 && search(2)) return true;
-    return search(1);
+    if (!search(1)) return false;
+    if (npad == 256 && out.WC == 1 && wk_env == 2) out.WK = 2;   // two waves per SIMD splitting the K loop
+    return true;
 }
 
 // ---- row-split cluster form: plan, workspace, launch
@@ -1120,6 +1208,11 @@ hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, con
     a.Zsrc = dZ; a.mu = dmu; a.src_kind = src_kind;
     a.q = q; a.d_ub = d_ub; a.tc = tc; a.ipw = pl.ipw; a.store = store ? 1 : 0; a.nslot = pl.nslot; a.tol = tol;
     if (pl.WC == 2 && pl.MT == 4 && pl.NT == 2) return launch_one<4, 2, 2>(st, a, pl.nblocks, pl.lds_bytes);
+    if (pl.WK == 2 && pl.MT == 4 && pl.WC == 1) {
+        if (pl.NT == 1) return launch_one<4, 1, 1, 2>(st, a, pl.nblocks, pl.lds_bytes);
+        if (pl.NT == 2) return launch_one<4, 2, 1, 2>(st, a, pl.nblocks, pl.lds_bytes);
+        if (pl.NT == 3) return launch_one<4, 3, 1, 2>(st, a, pl.nblocks, pl.lds_bytes);
+    }
     const int key = pl.MT * 10 + pl.NT;
     switch (key) {
         case 41: return launch_one<4, 1>(st, a, pl.nblocks, pl.lds_bytes);
