@@ -11,7 +11,7 @@ OBJS  := $(addprefix $(CSRC)/,dto_kernels.$(O) dto_small.$(O) dto_sweep_fused.$(
 
 all: $(LIB)
 
-$(CSRC)/dto_kernels.$(O): $(CSRC)/dto_kernels.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h $(CSRC)/dto_hostxfer.h
+$(CSRC)/dto_kernels.$(O): $(CSRC)/dto_kernels.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h $(CSRC)/dto_gemm_ring.hip.h $(CSRC)/dto_hostxfer.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/dto_small.$(O): $(CSRC)/dto_small.hip $(CSRC)/dto_kernels.h
