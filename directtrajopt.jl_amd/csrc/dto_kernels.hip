@@ -930,7 +930,9 @@ static void launch_bgemm(hipStream_t st, const BGemmArgs& a) {
     // 256x500 equal, 256x1000 and 512x100 +5..7 % with 128-tiles (DTO_BGEMM_TILE64=0/1 forces).
     static const int force64 = tune_int("DTO_BGEMM_TILE64", -1);
     const long t128 = a.npad / 128;
-    const bool small_launch = force64 >= 0 ? force64 != 0 : t128 * t128 * t128 * a.nbatch < 3500;
+    // (with the ring core the 128-tiles win at every launch size from 256 states on, even 30 intervals: 256 x 250 2.12 -> 2.07 ms,
+    // 256 x 100 1.35 -> 1.26 per Jacobian; at 128 states, one tile per matrix, the crossover stands -- gpurun_out/r03ag/ab_tile*.log)
+    const bool small_launch = force64 >= 0 ? force64 != 0 : (t128 == 1 && a.nbatch < 3500);
     if (a.npad % 128 == 0 && small_launch && bgemm_shape_choice() < 0) {
         launch_bgemm_shape<GemmShape<64, 64, 2, 2, 16>, EPI>(st, a, 4);
         return;
