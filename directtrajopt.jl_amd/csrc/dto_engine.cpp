@@ -88,6 +88,11 @@ struct BilHost {
     unsigned* xch_arrive[2] = {nullptr, nullptr};
     size_t xch_cap[2] = {0, 0};
     int xch_clusters[2] = {0, 0};
+    // generator-stationary sweeps (dto_sweep_gs.hip): partial-norm slabs and arrival counters per sweep buffer, grow-only
+    double* gs_xn[2] = {nullptr, nullptr};
+    unsigned* gs_arrive[2] = {nullptr, nullptr};
+    size_t gs_xn_cap[2] = {0, 0};
+    int gs_groups[2] = {0, 0};
     bool small = false;       // n <= 32: fused one-workgroup-per-interval path (dto_small.hip)
     double* d_Gs = nullptr;   // compact generators for that path
     bool use_basis = false;   // A^2..A^4 from the generator subspace instead of three batched GEMMs
@@ -578,6 +583,8 @@ int fused_sweep_steps(dto_handle* h, const SweepBuf& w, int d_ub, hipStream_t st
 bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store);
 bool cluster_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
                            ClusterSweepPlan& cp);
+bool gs_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
+                      bool shared_chip, GsSweepPlan& gp);
 bool ensure_bind_runs(dto_handle* h, int which);
 
 // Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
@@ -596,9 +603,31 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
     static const int tc_env = tune_int("DTO_SWEEP_TC", -1);
     int tc = tc_env >= 0 ? tc_env : plan.d_ub / 2 - 1;
     if (tc < 2) tc = 0;
+    // Generator-stationary form (dto_sweep_gs.hip, round 4): clusters of npad / 32 workgroups with the generators resident in
+    // their registers; serves what the single-workgroup form cannot fill the chip with -- single-column sweeps (eval_constraint,
+    // the Hessian's forward column), short shards -- see gs_sweep_applies.
+    GsSweepPlan gp;
+    if (!skip_init && gs_sweep_applies(h, b, w, ty, plan, store, shared_chip, gp)) {
+        const int wi = &w == &b.ad ? 1 : 0;
+        const size_t need = sweep_gs_norm_doubles(gp);
+        if (need > b.gs_xn_cap[wi] || gp.n_groups > b.gs_groups[wi]) {
+            b.gs_xn[wi] = own(h, dalloc<double>(need));
+            b.gs_arrive[wi] = own(h, dalloc<unsigned>((size_t)(gp.n_groups + 3) / 4 * 4));
+            b.gs_xn_cap[wi] = need;
+            b.gs_groups[wi] = gp.n_groups;
+        }
+        w.nblk = gp.ipw;
+        HIP_CHECK(hipMemsetAsync(w.stats, 0, 4 * sizeof(int32_t), st));
+        {
+            ProfScope ps(h, st, prof_cat, flops_step * plan.d_ub);
+            HIP_CHECK(launch_sweep_gs(st, h->P, b.k, w, ty, gp, b.gs_xn[wi], b.gs_arrive[wi], dZ, dmu, src_kind, transposed, plan.d_ub, tc,
+                                      store, 1.1e-16));
+        }
+        if (!want_steps) return plan.d_ub;
+        return fused_sweep_steps(h, w, plan.d_ub, st);
+    }
     // Fused form (dto_sweep_fused.hip): the whole series in one persistent launch, a workgroup per few intervals.  The
-    // step-per-launch form below remains for single-type sweeps (split-K over the generators serves those better), for
-    // sweeps over frozen p terms and for the products' extra start vector.
+    // step-per-launch form below remains for sweeps over frozen p terms and for the products' extra start vector.
     FusedSweepPlan fp;
     if (!skip_init && fused_sweep_applies(h, b, w, ty, plan, store) && sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp, shared_chip)) {
         w.nblk = fp.ipw;
@@ -943,6 +972,26 @@ bool cluster_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf
     return sweep_cluster_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, cp);
 }
 
+// The generator-stationary form needs the whole chip to itself (one 512-register workgroup per CU, all cluster members resident):
+// not beside the chain (`shared_chip`), not with sub-stepping, frozen p terms or the products' extra start vector.  It is taken
+// where the single-workgroup form cannot fill the chip: single-column sweeps and sweeps the fused planner refuses (short shards);
+// measured (tools/sweep_gs_probe, 256 states): p column of 2000 knots 0.77 ms against 1.38 ms for the split-K step launches,
+// Jacobian sweep of 250 knots 0.80 against 1.15 ms for the row-split cluster form.
+bool gs_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
+                      bool shared_chip, GsSweepPlan& gp) {
+    static const int on = tune_int("DTO_SWEEP_GS", 1);  // A/B runs (TUNING builds): 0 = never, 2 = wherever it can run
+    if (!on || h->sweep_form == 1 || w.frozen || plan.q != 1 || h->n_cu < 64) return false;
+    if (shared_chip && on != 2) return false;
+    if (store && !(w.Zt && plan.d_ub + 1 <= w.dcap)) return false;
+    if (store && ty.T == 1 && h->reuse) return false;   // (a frozen sweep reads nterms_p in blocks of TN intervals)
+    if ((size_t)ty.T * w.Kpad * w.npad * 8 >= (1ull << 31)) return false;   // 32-bit buffer offsets into a term slab
+    if (!sweep_gs_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, gp)) return false;
+    if (on == 2) return true;
+    if (ty.T == 1) return true;
+    FusedSweepPlan fp;
+    return !sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp);
+}
+
 // max_k ||A_k^2||_1^(1/2), exact, for callbacks that do not run the propagator chain: A_k and A_k^2 only
 // (one streaming pass + one small GEMM per chunk).  Sharper than the generator-norm bound, so the sweep
 // usually needs a single round (q = 1).
@@ -1189,7 +1238,9 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 // cheaper than the step-per-launch form the frozen variant needs (256 x 2000: 10.9 against 12.0 ms per Jacobian);
                 // the stored p terms stay valid for a Hessian at this point either way (a sweep without store leaves them alone)
                 ClusterSweepPlan cp_unused;
-                const bool one_launch = fused_sweep_applies(h, b, b.fw, ty, plan, false) || cluster_sweep_applies(h, b, b.fw, ty, plan, false, cp_unused);
+                GsSweepPlan gp_unused;
+                const bool one_launch = fused_sweep_applies(h, b, b.fw, ty, plan, false) || cluster_sweep_applies(h, b, b.fw, ty, plan, false, cp_unused) ||
+                                        gs_sweep_applies(h, b, b.fw, ty, plan, false, overlap && !h->deterministic, gp_unused);
                 if (have_p && !one_launch) {
                     // sweep the tangent columns alone, their inhomogeneous terms read the stored p terms
                     SweepBuf wf = b.fw;
@@ -1254,7 +1305,11 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             // forward sweep of the p column a host-driven sequence of small launches -- independent until the pairing kernels,
             // so the adjoint sweep is enqueued first and the forward sweep runs next to it on the second stream.
             const bool fwd_needed = pair && !(same && (b.cache_kind == 3 || b.p_terms));
-            const bool side_by_side = fwd_needed && h->overlap_sweep && fused_sweep_applies(h, b, b.ad, ty1, plan, true);
+            // (a generator-stationary forward sweep takes the whole chip for a fraction of the time the step launches needed: it
+            // runs first, alone, and the adjoint sweep after it in the shape it has alone on the chip)
+            GsSweepPlan gp_fw;
+            const bool fwd_gs = fwd_needed && gs_sweep_applies(h, b, b.fw, make_types(0, false), plan, true, false, gp_fw);
+            const bool side_by_side = fwd_needed && !fwd_gs && h->overlap_sweep && fused_sweep_applies(h, b, b.ad, ty1, plan, true);
             bool adjoint_enqueued = false;
             if (side_by_side) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ, dmu and the zeroed slab are ready here
@@ -1768,6 +1823,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
             HIP_CHECK(sweep_fused_prepare());
             HIP_CHECK(sweep_cluster_prepare());
+            HIP_CHECK(sweep_gs_prepare());
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;

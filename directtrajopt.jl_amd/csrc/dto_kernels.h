@@ -258,6 +258,23 @@ hipError_t launch_sweep_cluster(hipStream_t st, const KProb& P, const KBil& B, c
                                 const ClusterSweepPlan& pl, double* X, unsigned* arrive, const double* dZ, const double* dmu,
                                 int src_kind, int transposed, int q, int d_ub, int tc, bool store, double tol);
 
+// ---- the sweep with the generators STATIONARY in registers (dto_sweep_gs.hip, round 4): a cluster of npad / 32 workgroups shares an
+// interval group, each member holding 32 rows of every generator for the whole launch; only the term slices move (through the
+// sweep's own term slabs, sc1 on both sides).  128 and 256 states, at most 4 drives, no sub-stepping (q = 1).
+struct GsSweepPlan {
+    int KU, MP, NT, ipw, has_src, n_groups, n_clusters, nblocks;
+    size_t lds_bytes;
+    double term_us;  // the cost model's time per Taylor term
+};
+hipError_t sweep_gs_prepare();
+bool sweep_gs_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, GsSweepPlan& out);
+size_t sweep_gs_norm_doubles(const GsSweepPlan& pl);   // exchange slab of the partial column norms
+// arrive: n_groups (rounded up to 4) counters, zeroed by the launch; terms into w.Zt (store) or ping-pong w.Z[0/1], sums into w.S,
+// valid term counts into w.nterms[group], w.stats as launch_sweep_fused
+hipError_t launch_sweep_gs(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty, const GsSweepPlan& pl,
+                           double* Xn, unsigned* arrive, const double* dZ, const double* dmu, int src_kind, int transposed, int d_ub,
+                           int tc, bool store, double tol);
+
 void launch_sweep_step(hipStream_t st, const KBil& B, const SweepBuf& w, const SweepTypes& ty, int transposed,
                        int t, int in_buf, int split_store = 0);
 void launch_sweep_check(hipStream_t st, const SweepBuf& w, int T, int t, double tol);
