@@ -1257,9 +1257,14 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 const bool keep = h->reuse && b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap && !have_p;
                 // (option "deterministic": the sweep keeps the shape it has when it runs alone, so the bits do not depend on
                 // overlap_sweep; next to the chain the 256-state sweep otherwise groups its intervals by twelve instead of nine)
-                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, ss, keep, false, false,
-                                            /*shared_chip=*/overlap && !h->deterministic);
-                launch_apply_Gu(ss, b.k, b.fw, 0, b.fw.S, b.fw.GY);
+                // (a short shard's sweep in the generator-stationary form wants the chip to itself for a fraction of a millisecond: it
+                // follows the chain on the call's stream instead of sharing the chip with it)
+                GsSweepPlan gp_j;
+                const bool gs_alone = gs_sweep_applies(h, b, b.fw, ty, plan, keep, false, gp_j);
+                hipStream_t sw = gs_alone ? st : ss;
+                const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, sw, keep, false, false,
+                                            /*shared_chip=*/overlap && !h->deterministic && !gs_alone);
+                launch_apply_Gu(sw, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
                 if (keep || plan.q > 1) b.p_terms = false;  // the store now holds every column type / the scale factors changed
@@ -1305,11 +1310,10 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             // forward sweep of the p column a host-driven sequence of small launches -- independent until the pairing kernels,
             // so the adjoint sweep is enqueued first and the forward sweep runs next to it on the second stream.
             const bool fwd_needed = pair && !(same && (b.cache_kind == 3 || b.p_terms));
-            // (a generator-stationary forward sweep takes the whole chip for a fraction of the time the step launches needed: it
-            // runs first, alone, and the adjoint sweep after it in the shape it has alone on the chip)
-            GsSweepPlan gp_fw;
-            const bool fwd_gs = fwd_needed && gs_sweep_applies(h, b, b.fw, make_types(0, false), plan, true, false, gp_fw);
-            const bool side_by_side = fwd_needed && !fwd_gs && h->overlap_sweep && fused_sweep_applies(h, b, b.ad, ty1, plan, true);
+            // (where the adjoint sweep has no single-workgroup form -- short shards -- both sweeps take the generator-stationary form,
+            // one after the other; beside a fused adjoint sweep the forward column keeps its step launches, which fit into the CUs
+            // that sweep leaves idle: measured 5.5 against 5.9 ms at 256 x 2000 with the forward column first and alone)
+            const bool side_by_side = fwd_needed && h->overlap_sweep && fused_sweep_applies(h, b, b.ad, ty1, plan, true);
             bool adjoint_enqueued = false;
             if (side_by_side) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ, dmu and the zeroed slab are ready here
@@ -1330,7 +1334,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                     steps_f = b.p_steps;      // eval_constraint (or an earlier Hessian) stored the p terms of this point
                 } else {
                     Tf = 1;
-                    steps_f = run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, plan, sf, true);
+                    steps_f = run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, plan, sf, true, false, false, /*shared_chip=*/side_by_side);
                     b.cache_kind = h->reuse ? 1 : 0;  // the p sums are valid, the tangent sums are not
                     b.cache_steps = steps_f;
                     remember_p_terms(h, b, true, steps_f, sf);

@@ -262,7 +262,7 @@ hipError_t launch_sweep_cluster(hipStream_t st, const KProb& P, const KBil& B, c
 // interval group, each member holding 32 rows of every generator for the whole launch; only the term slices move (through the
 // sweep's own term slabs, sc1 on both sides).  128 and 256 states, at most 4 drives, no sub-stepping (q = 1).
 struct GsSweepPlan {
-    int KU, MP, NT, ipw, has_src, n_groups, n_clusters, nblocks;
+    int KU, MP, NT, ipw, has_src, n_groups, n_clusters, nblocks, cap;
     size_t lds_bytes;
     double term_us;  // the cost model's time per Taylor term
 };

@@ -97,13 +97,19 @@ int main(int argc, char** argv) {
     if (nt_over > 0) {
         gp.NT = nt_over; gp.ipw = 16 * nt_over / ty.T; gp.n_groups = (K + gp.ipw - 1) / gp.ipw;
         gp.n_clusters = std::min(32, (gp.n_groups + 7) / 8 * 8); gp.nblocks = gp.n_clusters * gp.KU;
-        gp.lds_bytes = gs_lds_bytes(gp.KU, gp.MP, gp.NT);
+        gp.cap = (gp.n_groups + gp.n_clusters - 1) / gp.n_clusters * gp.ipw;
+        gp.lds_bytes = gs_lds_bytes(gp.KU, gp.MP, gp.NT, gp.cap);
     }
     printf("gs plan: KU=%d MP=%d NT=%d ipw=%d has_src=%d groups=%d clusters=%d blocks=%d lds=%zu  model %.1f us/term\n", gp.KU, gp.MP, gp.NT, gp.ipw,
            gp.has_src, gp.n_groups, gp.n_clusters, gp.nblocks, gp.lds_bytes, gp.term_us);
     double* Xn; unsigned* arrive;
     CK(hipMalloc(&Xn, sweep_gs_norm_doubles(gp) * 8));
     CK(hipMalloc(&arrive, 4 * (size_t)((gp.n_groups + 3) / 4 * 4)));
+#ifdef GS_STAMP
+    unsigned long long* d_stamp;
+    CK(hipMalloc(&d_stamp, 64 * 8 * 8)); CK(hipMemset(d_stamp, 0, 64 * 8 * 8));
+    gs_stamp_buffer = d_stamp;
+#endif
     for (int rep = 0; rep < 5; ++rep) {
         CK(hipMemset(wg.stats, 0, 16));
         CK(hipEventRecord(e0));
@@ -115,6 +121,19 @@ int main(int argc, char** argv) {
         if (rep >= 2) printf("  gs     %.3f ms  nonconv=%d max_terms=%d  (%.1f TF/s at max_terms, %.2f us/term)\n", ms, st[0], st[1],
                              flops_term * (st[1] - 1) / ms * 1e-9, ms * 1e3 / (st[1] - 1));
     }
+#ifdef GS_STAMP
+    {
+        std::vector<unsigned long long> st(64 * 8);
+        CK(hipMemcpy(st.data(), d_stamp, st.size() * 8, hipMemcpyDeviceToHost));
+        printf("phase stamps of block 0 (cycles): item: B1 issue mfma land+B2 partials+B3 reduce+publish drain+signal | total\n");
+        for (int i = 4; i < 24; ++i) {
+            if (!st[i * 8 + 7]) break;
+            printf("  item %2d:", i);
+            for (int k = 1; k < 8; ++k) printf(" %6llu", st[i * 8 + k] - st[i * 8 + k - 1]);
+            printf(" | %6llu   gap to next %6llu\n", st[i * 8 + 7] - st[i * 8], st[(i + 1) * 8] ? st[(i + 1) * 8] - st[i * 8 + 7] : 0ull);
+        }
+    }
+#endif
     if (have_fused) {
         // compare the sums (and stored terms): both forms stop per group on the same test but with different groupings, so terms
         // below 1e-16 of the sum may differ -- compare relative to the column's scale
