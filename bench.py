@@ -180,6 +180,32 @@ def other_callbacks(dto_amd, torch, prob, ev_jac, dev, Z, stream, N):
                              "measured_in": "serial pass (overlap_sweep = 0), HIP events on the launch stream"}
         h["callback_hbm"] = {"algorithmic_bytes": nbytes, "achieved": nbytes / (h["ms_per_call"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": nbytes / (h["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # What Ipopt itself sees: the host-pointer entry points (dto_eval_jacobian / dto_eval_hessian: Z and mu from host memory, the
+        # value vector into the solver's pageable host vector -- PCIe in both directions inside the call).  Never part of `value`.
+        try:
+            import numpy as np
+            Zn = prob.trajectory.vec()
+            mun = np.ones(ev.n_constraints)
+            hp = {}
+            jac_h = np.empty(ev.n_jacobian_entries)
+            hes_h = np.empty(ev.n_hessian_entries)
+            for name, fn, nbytes in (("eval_constraint_jacobian", lambda: ev.eval_constraint_jacobian(jac_h, Zn), jac_h.nbytes),
+                                     ("eval_hessian_lagrangian", lambda: ev.eval_hessian_lagrangian(hes_h, Zn, 1.0, mun), hes_h.nbytes)):
+                fn()
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                hp[name] = {"ms_per_call_median": ts[1] * 1e3, "knot_points_per_s": N / ts[1], "value_vector_bytes": nbytes,
+                            "calls_timed": 3}
+            hp["note"] = ("host pointers in and out, PCIe included: only the entries that can change cross PCIe (csrc/dto_hostxfer.*), the -E_k "
+                          "blocks while the GPU still computes; the rest of the caller's vector is filled by host threads")
+            out["host_pointer"] = hp
+            del jac_h, hes_h
+        except Exception as e:  # a report, never fatal
+            out["host_pointer"] = {"error": repr(e)}
         # One interior-point iteration as Ipopt / MadNLP drive it: constraint, objective gradient, Jacobian and Hessian at a NEW
         # point each time (nothing is carried from one point to the next), without and with option reuse_forward_sweep, under
         # which the callbacks of one point share the forward sweep.  A report, never part of `value`.
@@ -469,11 +495,15 @@ def main():
 
     # the dominant kernel of the callback: the propagator chain's batched GEMM (Jacobian), the adjoint generator sweep (Hessian:
     # one persistent k_sweep_fused launch, 3.7 of 5.7 ms at 256 x 2000)
-    dominant = "expmv_adjoint" if args.callback == "hessian" else "bgemm"
+    dominant = {"hessian": "expmv_adjoint", "constraint": "expmv"}.get(args.callback, "bgemm")
+
+    n_int = max(0, min(k_hi, N_total - 1) - k_lo + 1)   # intervals this rank owns
 
     def collect():
         """HIP-event figures of the engine's kernels since the last profile_reset."""
         ms_g, n_g, fl_g = ev.profile_get(dominant)
+        # launches of one kind per call = chain chunks (one unless the workspace budget splits the intervals)
+        chunks = max(1, round(ev.profile_get("build_A")[1] / max(1, args.steps)))
         ms_s, n_s, fl_s = ev.profile_get("expmv")
         var = {}
         for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("basis", "basis")):
@@ -484,13 +514,30 @@ def main():
                 # matrices in the epilogue and one or two outputs -- seven npad x npad matrices per interval in each of the
                 # three launches of the order-26 form; a squaring moves two
                 streams = {"horner": 7, "square": 2}.get(key)
-                if streams and (n, Nk) == (256, 2000):
-                    gbs = streams * 8.0 * n * n * (Nk - 1) / (ms_v / n_v * 1e-3) / 1e9
-                    var[key].update({"algorithmic_hbm_bytes": streams * 8.0 * n * n * (Nk - 1), "hbm_gbs": gbs,
-                                     "hbm_frac": gbs / HBM_PEAK_GBS})
-        return ms_g, n_g, fl_g, ms_s, n_s, fl_s, var
+                if streams:
+                    npad = -(-n // 64) * 64
+                    per_launch = streams * 8.0 * npad * npad * max(n_int, 1) / max(1, chunks)
+                    gbs = per_launch / (ms_v / n_v * 1e-3) / 1e9
+                    var[key].update({"algorithmic_hbm_bytes": per_launch, "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+        # the bandwidth-bound assembly kernels: achieved HBM GB/s from HIP events and their algorithmic bytes (north_star:
+        # "achieved HBM GB/s for the bandwidth-bound assembly")
+        asm = {}
+        for key, nm, what in (("zero_fill", "zero_fill", "fill!(., 0) of the value slab (k_jac_zero skips the -E_k blocks the chain overwrites; the Hessian's is a memset)"),
+                              ("build_A", "build_A", "A_k = dt (G_0 + sum_j u_j G_j): one matrix written per interval (k_build_A)"),
+                              ("basis_multi", "basis_multi", "A^2, A^3, A^4 from the generator subspace in one launch: three matrices written per interval (k_basis_gemm_multi)"),
+                              ("tangent_columns", "assembly", "tangent columns and identity blocks of the bilinear Jacobian (k_jac_bilinear)")):
+            ms_v, n_v, by_v = ev.profile_get(nm)
+            if not n_v or ms_v <= 0:
+                continue
+            if key == "basis_multi":  # the engine prices this launch in flops; its bytes: three output matrices per interval
+                npad = -(-n // 64) * 64
+                by_v = 3 * 8.0 * npad * npad * n_int * args.steps
+            gbs = by_v / (ms_v * 1e-3) / 1e9
+            asm[key] = {"kernel": what, "launches": n_v, "avg_launch_ms": ms_v / n_v, "algorithmic_bytes_per_launch": by_v / n_v,
+                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        return ms_g, n_g, fl_g, ms_s, n_s, fl_s, var, asm
 
-    ms_gemm, n_gemm, fl_gemm, ms_sweep, n_sweep, fl_sweep, variants = collect()
+    ms_gemm, n_gemm, fl_gemm, ms_sweep, n_sweep, fl_sweep, variants, assembly = collect()
     # In the timed region the Jacobian's generator sweep shares the chip with the chain's products (option overlap_sweep, on
     # by default): a kernel's HIP-event duration there includes what it waited for the other stream.  The roofline of the
     # dominant kernel is therefore taken from a SERIAL pass -- the same K steps again with overlap_sweep = 0, one kernel at
@@ -515,10 +562,15 @@ def main():
         serial_elapsed = time.perf_counter() - t0
         ev.profile_enable(False)
         ev.set_option("overlap_sweep", 1)
-        ms_gemm, n_gemm, fl_gemm, ms_sweep, n_sweep, fl_sweep, variants = collect()
+        ms_gemm, n_gemm, fl_gemm, ms_sweep, n_sweep, fl_sweep, variants, assembly = collect()
         overlapped["ms_per_step_serial_pass"] = serial_elapsed / args.steps * 1e3
     smax, terms = ev.last_stats()
     finite = bool(torch.isfinite(out).all().item())
+    if args.callback == "constraint" and n_gemm:
+        # the engine prices a one-launch sweep by its step BUDGET; the roofline takes the products of the Taylor terms actually run:
+        # 2 npad^2 (m + 1) flops per interval and term (terms - 1 products: term 0 is the state itself)
+        npad = -(-n // 64) * 64
+        fl_gemm = 2.0 * npad * npad * (m + 1) * n_int * max(terms - 1, 1) * n_gemm
 
     # The blocks below are reports next to `value` (gather, strong scaling).  With several ranks they run collectives that
     # have never executed on an 8-GPU node: should one of them hang, every rank leaves after WATCHDOG_S seconds and rank 0
@@ -538,9 +590,11 @@ def main():
                     "config": {"workload": f"configs[2]: {n}-state bilinear, {m} drives, N={N_total} knots over {world} GPU(s), "
                                            f"callback={args.callback}", "knots_per_gpu": Nk, "knots_total": N_total,
                                "parallelism": f"knot-range shards x{world}"},
+                    "status": "collective_timeout",
                     "watchdog": f"the gather / strong-scaling reports did not finish within {WATCHDOG_S} s; `value` is the "
                                 "compute-only headline measured before them"}), flush=True)
-            os._exit(0)
+            # the line above keeps the headline, the exit code says that a collective hung: never report success for it
+            os._exit(3)
 
         watchdog = threading.Timer(WATCHDOG_S, bail)
         watchdog.daemon = True
@@ -579,6 +633,18 @@ def main():
             torch.cuda.synchronize(dev)
             step_ms.append((time.perf_counter() - t0) * 1e3)
 
+    # ... and the same with the host-to-device copy of Z inside each timed step (SURVEY.md section 8d's metric definition)
+    h2d_ms = []
+    if args.callback == "jacobian" and world == 1:
+        Zh = torch.from_numpy(prob.trajectory.vec()).pin_memory()
+        for _ in range(args.steps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            Z.copy_(Zh, non_blocking=True)
+            ostep()
+            torch.cuda.synchronize(dev)
+            h2d_ms.append((time.perf_counter() - t0) * 1e3)
+
     # The same K steps into a BOUND output vector (dto_bind_output_dev: what a solver in GPU mode, which hands the engine the same
     # device vector every iteration, can declare): the call-invariant half of the slab is then written once, not per call.
     # Reported next to `value`, never as `value` -- the headline keeps the reference's semantics (every entry written per call).
@@ -601,8 +667,10 @@ def main():
     traffic, traffic_src, traffic_call = None, None, None
     try:  # HBM bytes per launch of the dominant kernel come from committed PMC passes (bench.py cannot run rocprofv3 on itself)
         import glob
-        tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_traffic*.json")))[-1]))  # the latest round's
-        if (n, Nk, args.callback) == (256, 2000, "jacobian"):
+        # the latest round's passes for THIS shape and callback (profiles/rNN*_traffic_<callback>_<n>x<knots>.json), else none
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]*_traffic_{args.callback}_{n}x{Nk}.json")))
+        if cands:
+            tj = json.load(open(cands[-1]))
             traffic, traffic_src = tj["avg_per_launch_bytes"], tj["source"]
             traffic_call = tj.get("per_call_total_bytes")
             pl = tj["per_launch_bytes"]
@@ -639,8 +707,9 @@ def main():
                        "inputs": "Z and the value slab resident in HBM; the 4.2 MB host-to-device copy of Z that SURVEY.md §8d's "
                                  "metric lists is NOT in `value` (host-pointer figures: DESIGN.md §5)"},
             "roofline": {
-                "bound": "mfma", "kernel": ("k_sweep_fused (adjoint generator sweep of the Hessian: exp(A')mu and its u-tangents, one persistent launch)"
-                                            if args.callback == "hessian" else "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
+                "bound": "mfma", "kernel": {"hessian": "k_sweep_fused / k_sweep_gs (adjoint generator sweep of the Hessian: exp(A')mu and its u-tangents, one persistent launch)",
+                                            "constraint": "k_sweep_gs / k_sweep (generator sweep of the p column: exp(A)x)"}.get(
+                                                args.callback, "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 # HBM-side bytes of ALL kernels of one call from the same PMC passes, against SURVEY.md §8d's algorithmic bytes
@@ -670,6 +739,15 @@ def main():
                 (2.0 * (-(-n // 64) * 64) ** 2 * (-(-(Nk - 1) // 128) * 128) * (m + 1) * (m + 1) * terms * args.steps)
                 if args.callback == "jacobian" else fl_sweep),
         }
+        if assembly:
+            line["assembly_hbm"] = assembly
+        if h2d_ms:
+            hs = sorted(h2d_ms)
+            med = hs[len(hs) // 2] if len(hs) % 2 else 0.5 * (hs[len(hs) // 2 - 1] + hs[len(hs) // 2])
+            # SURVEY.md section 8d's literal definition: median wall time of one full callback INCLUDING the host-to-device copy of Z
+            line["value_incl_h2d_median"] = {"value": N_total / (med * 1e-3), "unit": "knot-points/s", "ms_per_step_median": med,
+                                             "includes": "H2D copy of Z from pinned host memory on the call's stream + the callback; "
+                                                         "values stay resident in HBM (D2H reported under host_pointer)"}
         if step_ms:
             ss = sorted(step_ms)
             line["ms_per_step_median"] = ss[len(ss) // 2] if len(ss) % 2 else 0.5 * (ss[len(ss) // 2 - 1] + ss[len(ss) // 2])
@@ -684,6 +762,8 @@ def main():
             # the other callbacks of the same problem, same protocol (3 untimed + 5 timed calls each): reported for
             # context (SURVEY.md §8d lists them next to the headline), never part of `value`
             line["other_callbacks"] = other_callbacks(dto_amd, torch, prob, ev, dev, Z, stream, N_total)
+            if "host_pointer" in line["other_callbacks"]:
+                line["host_pointer"] = line["other_callbacks"].pop("host_pointer")
         if world == 1 and not args.no_cpu_baseline and args.callback == "jacobian":
             try:
                 line["cpu_baseline"] = cpu_baseline(prob, n, m, Nk, args.cpu_budget)

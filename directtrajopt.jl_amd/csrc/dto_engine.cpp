@@ -329,7 +329,9 @@ struct ProfScope {
         h->prof.push_back(r);
     }
 };
-enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BGEMM_SQUARE = 4, CAT_SWEEP_ADJOINT = 5 };
+// (for the bandwidth-bound categories from CAT_ZERO on, `flops` carries the launch's algorithmic BYTES)
+enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BGEMM_SQUARE = 4, CAT_SWEEP_ADJOINT = 5,
+       CAT_ZERO = 6, CAT_BUILD_A = 7, CAT_ASSEMBLY = 8, CAT_BASIS_MULTI = 9 };
 
 // ------------------------------------------------------------------------------------------
 // structure
@@ -862,12 +864,15 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             double* css[3] = {w.colsum, w.colsum + cs_set, w.colsum + 2 * cs_set};
             // (A_k as a fourth, degree-1 set of the launch below instead of k_build_A's streaming pass: measured slower,
             // 1.15 against 0.79 + 0.22 ms -- 8000 more tiles with one K panel each)
-            launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+            {
+                ProfScope ps(h, st, CAT_BUILD_A, 8.0 * npad * (double)npad * nb);   // one matrix written per interval
+                launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+            }
             launch_basis_coef_multi(st, h->P, b.k, 3, b.basis, dZ, int0, nb, nbpad);
             {
                 // A^2, A^3, A^4 in one launch (tiles interleaved: the write-bound sets overlap the MFMA-bound one)
                 const double cols = b.basis[0].cntpad + b.basis[1].cntpad + b.basis[2].cntpad;
-                ProfScope ps(h, st, CAT_OTHER, 2.0 * npad * (double)npad * cols * nb);
+                ProfScope ps(h, st, CAT_BASIS_MULTI, 2.0 * npad * (double)npad * cols * nb);
                 launch_basis_gemm_multi(st, npad, nb, nbpad, 3, b.basis, outs, css);
             }
             launch_norm_from_colsum_multi(st, npad, nb, 3, css, w.norms);
@@ -1200,7 +1205,10 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
     // bound and primed output (dto_bind_output_dev): constants are in place, clear only the runs kernels accumulate into
     const bool keep_constants = h->bound[0] == dvals && h->primed[0] && ensure_bind_runs(h, 0);
     if (keep_constants) launch_zero_runs(st, h->d_bind_start[0], h->d_bind_len[0], h->n_bind_runs[0], dvals);
-    else if (!lone) HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
+    else if (!lone) {
+        ProfScope ps(h, st, CAT_ZERO, 8.0 * (double)h->info.jac_len);
+        HIP_CHECK(hipMemsetAsync(dvals, 0, sizeof(double) * (size_t)h->info.jac_len, st));
+    }
     h->last_terms = 0;
     const bool same = same_point(h, dZ, st);
     for (auto& b : h->bil) {
@@ -1268,13 +1276,23 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
                 if (keep || plan.q > 1) b.p_terms = false;  // the store now holds every column type / the scale factors changed
-            }, [&] { if (lone && !keep_constants) launch_jac_zero(st, h->P, b.k, dvals); });
+            }, [&] {
+                if (lone && !keep_constants) {
+                    // every entry but the -E_k blocks, which the chain overwrites
+                    ProfScope ps(h, st, CAT_ZERO, 8.0 * ((double)h->info.jac_len - (double)h->P.n_int * b.k.n * b.k.n));
+                    launch_jac_zero(st, h->P, b.k, dvals);
+                }
+            });
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_join, ss));
                 HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
             }
         }
-        launch_jac_bilinear(st, h->P, b.k, b.fw, dvals);
+        {
+            // tangent columns (m + 1 per interval: u_j and dt) and the identity of the z_{k+1} half
+            ProfScope ps(h, st, CAT_ASSEMBLY, 8.0 * (double)h->P.n_int * b.k.n * (b.k.m + 2 + b.k.m + 1));
+            launch_jac_bilinear(st, h->P, b.k, b.fw, dvals);
+        }
     }
     for (auto& d : h->der) launch_jac_derivative(st, h->P, d, dZ, dvals);
     for (size_t i = 0; i < h->ext_int.size(); ++i)
@@ -1290,7 +1308,10 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
     if (h->bound[1] == dH && h->primed[1] && ensure_bind_runs(h, 1))   // bound output: structural zeros are in place
         launch_zero_runs(st, h->d_bind_start[1], h->d_bind_len[1], h->n_bind_runs[1], dH);
     else
+    {
+        ProfScope ps(h, st, CAT_ZERO, 8.0 * (double)h->info.hess_len);
         HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, st));  // fill!(H, 0), evaluator.jl:571
+    }
     const bool same = same_point(h, dZ, st);
     // integrators in reference order (evaluator.jl:574-598)
     for (size_t i = 0; i < h->integ_kind.size(); ++i) {
@@ -2396,6 +2417,48 @@ int dto_shard_rows(const dto_handle* h, int64_t* start1, int64_t* len) {
     return 0;
 }
 
+// Cost model of one eval_constraint_jacobian per interval ("balanced by sum s_k if scaling counts vary"), host
+// arithmetic on Z with the norms of the generators the handle keeps: the same growth bounds the engine plans with (k_norm_bounds:
+// b1 >= ||A_k||_1 from ||G_j||_1, b2 >= ||A_k^2||_1^(1/2) from ||G_i G_j||_1 where the handle has them -- a GPU handle), turned into
+// squaring counts of the cheaper evaluation form, the Taylor terms of the sweep and their flop counts.
+int dto_interval_costs(const dto_handle* h, const double* Z, int64_t first, int64_t count, double* cost) {
+    if (!h || !Z || !cost || first < 0 || count < 0 || first + count > h->K) return 1;
+    for (int64_t i = 0; i < count; ++i) cost[i] = 0.0;
+    for (const BilHost& b : h->bil) {
+        const int m1 = b.k.m + 1;
+        const double np = b.k.npad, gemm = 2.0 * np * np * np;
+        // multisets of sizes 2..4 (and 0..4 for the factor K) over m + 1 generators: the generator-subspace GEMMs
+        const double c2 = m1 * (m1 + 1) / 2.0, c3 = c2 * (m1 + 2) / 3.0, c4 = c3 * (m1 + 3) / 4.0;
+        const double basis = b.small ? 0.0 : 2.0 * np * np * (2.0 * (c2 + c3 + c4) + 1 + m1);
+        for (int64_t i = 0; i < count; ++i) {
+            const double* zk = Z + (first + i) * h->z;
+            const double dt = std::fabs(zk[h->P.dt_idx]);
+            double ub[MAX_DRIVES + 1];
+            ub[0] = 1.0;
+            for (int j = 0; j < b.k.m; ++j) ub[j + 1] = std::fabs(zk[b.k.u_off + j]);
+            double b1 = 0.0, s2 = 0.0;
+            for (int a = 0; a < m1; ++a) {
+                b1 += ub[a] * b.g1[a];
+                if ((int)b.n2.size() == m1 * m1)
+                    for (int c = 0; c < m1; ++c) s2 += ub[a] * ub[c] * b.n2[a * m1 + c];
+            }
+            b1 *= dt;
+            double alpha = b1;
+            if ((int)b.n2.size() == m1 * m1) alpha = std::min(b1, dt * std::sqrt(s2));
+            if (!(alpha == alpha) || alpha > 1e6) alpha = 1e6;
+            const double sq2 = alpha > THETA_16 ? std::ceil(std::log2(alpha / THETA_16)) : 0.0;
+            const double sq3 = alpha > THETA_3P ? std::ceil(std::log2(alpha / THETA_3P)) : 0.0;
+            const double products = std::min(2.0 + sq2, 3.0 + sq3);
+            const SweepPlan sp = plan_sweep(alpha);
+            const double sweep = 2.0 * np * np * m1 * m1 * (double)sp.d_ub * sp.q;
+            cost[i] += b.small ? 2.0 * b.k.n * (double)b.k.n * b.k.n * (6.0 + sq2) : gemm * products + basis + sweep;
+        }
+    }
+    // every other term kind costs O(z) per knot: a constant that keeps intervals without a bilinear integrator from counting as free
+    for (int64_t i = 0; i < count; ++i) cost[i] += 64.0 * h->z;
+    return 0;
+}
+
 int dto_jacobian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols) {
     if (!h || !rows || !cols || first < 0 || count < 0 || first + count > h->jac_nnz) return 1;
     if (count == 0) return 0;
@@ -2882,12 +2945,17 @@ int dto_profile_reset(dto_handle* h) {
 int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops) {
     return guarded(h, [&] {
         int cat = -1;
-        bool any_gemm = false;
+        bool any_gemm = false, any_basis = false;
         if (!strcmp(name, "bgemm")) any_gemm = true;
         else if (!strcmp(name, "bgemm_horner")) cat = CAT_BGEMM_HORNER;
         else if (!strcmp(name, "bgemm_square")) cat = CAT_BGEMM_SQUARE;
         else if (!strcmp(name, "bgemm_plain")) cat = CAT_BGEMM;
-        else if (!strcmp(name, "basis")) cat = CAT_OTHER;
+        else if (!strcmp(name, "basis")) any_basis = true;
+        else if (!strcmp(name, "basis_k")) cat = CAT_OTHER;
+        else if (!strcmp(name, "basis_multi")) cat = CAT_BASIS_MULTI;
+        else if (!strcmp(name, "zero_fill")) cat = CAT_ZERO;
+        else if (!strcmp(name, "build_A")) cat = CAT_BUILD_A;
+        else if (!strcmp(name, "assembly")) cat = CAT_ASSEMBLY;
         else if (!strcmp(name, "expmv")) cat = CAT_SWEEP;
         else if (!strcmp(name, "expmv_adjoint")) cat = CAT_SWEEP_ADJOINT;
         else if (strcmp(name, "all")) throw HipError{"dto_profile_get: unknown name"};
@@ -2895,7 +2963,8 @@ int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launch
         int64_t n = 0;
         for (auto& r : h->prof) {
             if (any_gemm && r.cat != CAT_BGEMM && r.cat != CAT_BGEMM_HORNER && r.cat != CAT_BGEMM_SQUARE) continue;
-            if (!any_gemm && cat >= 0 && r.cat != cat) continue;
+            if (any_basis && r.cat != CAT_OTHER && r.cat != CAT_BASIS_MULTI) continue;
+            if (!any_gemm && !any_basis && cat >= 0 && r.cat != cat) continue;
             HIP_CHECK(hipEventSynchronize(r.b));
             float t = 0;
             HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));

@@ -8,7 +8,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 6
+DTO_ABI_VERSION = 7
 FLAG_GENERAL_PATH_ONLY = 1
 INTEGRATOR_BILINEAR, INTEGRATOR_DERIVATIVE, INTEGRATOR_EXTERNAL, INTEGRATOR_TIME_DEPENDENT_BILINEAR = 1, 2, 3, 4
 OBJECTIVE_QUADRATIC, OBJECTIVE_LINEAR, OBJECTIVE_MINTIME, OBJECTIVE_KNOT_SQDIST, OBJECTIVE_EXTERNAL_KNOT, OBJECTIVE_KNOT_LOWRANK, OBJECTIVE_EXTERNAL_GLOBAL = 1, 2, 3, 4, 5, 6, 7
@@ -79,6 +79,7 @@ SYMBOLS = {
     "dto_features_available": (C.c_int, [H, c_int32_p, c_int32_p, c_int32_p]),
     "dto_get_shard_info": (C.c_int, [H, C.POINTER(ShardInfo)]),
     "dto_shard_rows": (C.c_int, [H, c_int64_p, c_int64_p]),
+    "dto_interval_costs": (C.c_int, [H, c_double_p, C.c_int64, C.c_int64, c_double_p]),
     "dto_jacobian_structure": (C.c_int, [H, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "dto_hessian_structure": (C.c_int, [H, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "dto_constraint_bounds": (C.c_int, [H, c_double_p, c_double_p]),

@@ -8,15 +8,48 @@ whole vector on every rank, and `allreduce_sum` is for the objective's partial s
 from __future__ import annotations
 
 
-def shard_ranges(N, world):
-    """Contiguous, balanced 1-based inclusive knot ranges [(k_lo, k_hi)] for `world` ranks."""
-    base, rem = divmod(N, world)
-    out, lo = [], 1
-    for r in range(world):
-        n = base + (1 if r < rem else 0)
-        out.append((lo, lo + n - 1))
-        lo += n
-    return out
+def shard_ranges(N, world, cost=None):
+    """Contiguous 1-based inclusive knot ranges [(k_lo, k_hi)] for `world` ranks: balanced by knot count, or -- given `cost`, the
+    per-interval cost model of the engine (Evaluator.interval_costs / dto_interval_costs, length N - 1: interval k belongs to knot
+    k) -- by cost: the contiguous partition with the smallest maximum rank cost ("balanced by sum s_k if
+    scaling counts vary").  Cost-balanced ranges are unequal in knots, so their slabs travel in the broadcast form of the gather."""
+    if cost is None:
+        base, rem = divmod(N, world)
+        out, lo = [], 1
+        for r in range(world):
+            n = base + (1 if r < rem else 0)
+            out.append((lo, lo + n - 1))
+            lo += n
+        return out
+    import numpy as np
+    c = np.concatenate([np.asarray(cost, dtype=np.float64), [0.0]])  # the last knot owns no interval
+    if c.size != N or world > N or not np.all(np.isfinite(c)) or np.any(c < 0):
+        raise ValueError("shard_ranges: cost must hold N - 1 finite non-negative entries and world <= N")
+    pre = np.concatenate([[0.0], np.cumsum(c)])
+
+    def parts(limit):
+        """greedy packing under `limit` per rank, every rank at least one knot and enough knots left for the ranks behind it"""
+        cuts, lo = [], 0
+        for r in range(world):
+            left = world - r - 1
+            hi = int(np.searchsorted(pre, pre[lo] + limit, side="right")) - 1   # knots lo .. hi-1 cost <= limit
+            hi = max(lo + 1, min(hi, N - left))
+            if r == world - 1:
+                hi = N
+            cuts.append((lo, hi))
+            lo = hi
+        return cuts, max(pre[b] - pre[a] for a, b in cuts)
+
+    lo_l, hi_l = max(float(c.max()), pre[-1] / world), float(pre[-1])
+    best = parts(hi_l)
+    for _ in range(60):   # bisection on the bottleneck cost
+        mid = 0.5 * (lo_l + hi_l)
+        cand = parts(mid)
+        if cand[1] <= mid * (1 + 1e-12):
+            best, hi_l = cand, mid
+        else:
+            lo_l = mid
+    return [(a + 1, b) for a, b in best[0]]
 
 
 def allgather_slabs(local, lens, group=None):

@@ -454,6 +454,15 @@ class Evaluator:
     def profile_reset(self):
         self._check(self._lib.dto_profile_reset(self._h))
 
+    def interval_costs(self, Z, first=0, count=None):
+        """Flop model of one eval_constraint_jacobian per interval (dto_interval_costs): input of cost-balanced sharding."""
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        K = self.trajectory.N - 1
+        count = K - first if count is None else count
+        out = np.empty(count)
+        self._check(self._lib.dto_interval_costs(self._h, Z.ctypes.data_as(capi.c_double_p), first, count, out.ctypes.data_as(capi.c_double_p)))
+        return out
+
     def profile_get(self, name):
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._check(self._lib.dto_profile_get(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(fl)))

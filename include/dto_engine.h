@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 6
+#define DTO_ABI_VERSION 7
 
 /* integrator kinds (src/integrators/) */
 #define DTO_INTEGRATOR_BILINEAR 1   /* bilinear_integrator.jl:61-85   */
@@ -204,6 +204,14 @@ int dto_get_shard_info(const dto_handle* h, dto_shard_info* out);
 /* local constraint buffer = concatenation of global row segments [start1 (1-based), len] */
 int dto_shard_rows(const dto_handle* h, int64_t* start1, int64_t* len);
 
+/* Cost model of one eval_constraint_jacobian for intervals first .. first+count-1 (0-based, GLOBAL numbering; Z is the whole NLP
+ * vector, host memory): flops from the growth bound of every interval's A_k = dt_k G(u_k) -- squarings of the propagator chain,
+ * Taylor terms of the sweep (bilinear_integrator.jl:81: `expv`'s work grows with ||dt G(u)|| too).  Host arithmetic only, also on
+ * structure-only handles: a caller that shards knot ranges over GPUs balances them by these instead of by knot
+ * count, so that on a pulse whose amplitude varies along the trajectory the slowest rank does not set the step; unequal ranges
+ * are gathered in the broadcast form (dto_get_gather_layout). */
+int dto_interval_costs(const dto_handle* h, const double* Z, int64_t first, int64_t count, double* cost);
+
 /* structure -- MOI.jacobian_structure (evaluator.jl:364) / MOI.hessian_lagrangian_structure (:385).
  * Writes entries [first, first+count) (0-based position in the GLOBAL CSC order), 1-based pairs. */
 int dto_jacobian_structure(const dto_handle* h, int64_t first, int64_t count, int64_t* rows, int64_t* cols);
@@ -366,8 +374,11 @@ int dto_profile_reset(dto_handle* h);
 /* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain: every template instance), its parts
  * "bgemm_horner" (the products with a fused polynomial epilogue) / "bgemm_square" / "bgemm_plain", "basis"
  * (generator-subspace GEMM), "expmv" (forward generator sweeps and the pairing products), "expmv_adjoint" (the Hessian's adjoint
- * sweep: its dominant kernel), "all".
- * Returns accumulated device milliseconds, launches and algorithmic FLOPs of those launches. */
+ * sweep: its dominant kernel), "all"; "basis_multi" / "basis_k" (the two generator-subspace launches apart: A^2..A^4, and the
+ * factor K), and the bandwidth-bound assembly kernels "zero_fill" (the Jacobian's / Hessian's fill!(., 0)), "build_A" (A_k from the
+ * generators), "assembly" (the writers of the bilinear Jacobian's tangent columns).
+ * Returns accumulated device milliseconds, launches and algorithmic FLOPs of those launches -- for the three assembly names the
+ * third output is the launches' algorithmic BYTES (what they must read and write), not FLOPs. */
 int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launches, double* flops);
 /* diagnostics of the last Jacobian call: max squarings used, Taylor terms used by the tangent sweep */
 int dto_last_stats(const dto_handle* h, int32_t* max_squarings, int32_t* expmv_terms);

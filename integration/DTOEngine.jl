@@ -38,7 +38,7 @@ using ..Constraints: AbstractNonlinearConstraint, NonlinearKnotPointConstraint, 
 using ..CommonInterface: evaluate!, eval_jacobian, eval_hessian_of_lagrangian
 
 const lib = get(ENV, "DTO_ENGINE_LIB", "libdto_engine.so")
-const DTO_ABI_VERSION = Int32(6)
+const DTO_ABI_VERSION = Int32(7)
 
 const DTO_INTEGRATOR_BILINEAR = Int32(1)
 const DTO_INTEGRATOR_DERIVATIVE = Int32(2)
@@ -657,6 +657,50 @@ gather_constraint_dev!(ev::GPUEvaluator, dg_local::Ptr{Float64}, dg_full::Ptr{Fl
     check(ev, @ccall lib.dto_gather_constraint_dev(ev.handle::Ptr{Cvoid}, dg_local::Ptr{Float64}, dg_full::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
 allreduce_objective_dev!(ev::GPUEvaluator, df::Ptr{Float64}, stream::Ptr{Cvoid}) =
     check(ev, @ccall lib.dto_allreduce_objective_dev(ev.handle::Ptr{Cvoid}, df::Ptr{Float64}, stream::Ptr{Cvoid})::Cint)
+
+"""
+Flop model of one `eval_constraint_jacobian` per interval (`dto_interval_costs`): squarings of the propagator chain and Taylor
+terms of the sweep from the growth bound of every `Δt_k G(u_k)` (the work of the reference's `expv`, bilinear_integrator.jl:81,
+grows with that norm as well).  `balanced_knot_ranges` turns it into contiguous knot ranges of equal cost for `world` ranks --
+SURVEY.md section 8e: on a pulse whose amplitude varies along the trajectory equal knot counts leave the slowest rank setting the
+step.  Ranges of unequal length are gathered in the broadcast form (`gather_layout` then reports `in_place_all_gather == 0`).
+"""
+function interval_costs(ev::GPUEvaluator, Z⃗::AbstractVector{Float64})
+    K = ev.trajectory.N - 1
+    cost = Vector{Float64}(undef, K)
+    Zc = convert(Vector{Float64}, Z⃗)
+    first0, cnt = Int64(0), Int64(K)
+    GC.@preserve Zc cost check(ev, @ccall lib.dto_interval_costs(ev.handle::Ptr{Cvoid}, Zc::Ptr{Float64}, first0::Int64, cnt::Int64, cost::Ptr{Float64})::Cint)
+    return cost
+end
+function balanced_knot_ranges(cost::AbstractVector{Float64}, world::Integer)
+    N = length(cost) + 1
+    c = vcat(cost, 0.0)                      # the last knot owns no interval
+    pre = vcat(0.0, cumsum(c))
+    function parts(limit)
+        cuts = Tuple{Int,Int}[]; lo = 0
+        for r in 1:world
+            left = world - r
+            hi = searchsortedlast(pre, pre[lo + 1] + limit) - 1
+            hi = max(lo + 1, min(hi, N - left))
+            r == world && (hi = N)
+            push!(cuts, (lo + 1, hi)); lo = hi
+        end
+        return cuts, maximum(pre[b + 1] - pre[a] for (a, b) in cuts)
+    end
+    lo_l, hi_l = max(maximum(c), pre[end] / world), pre[end]
+    best = parts(hi_l)
+    for _ in 1:60
+        mid = (lo_l + hi_l) / 2
+        cand = parts(mid)
+        if cand[2] <= mid * (1 + 1e-12)
+            best, hi_l = cand, mid
+        else
+            lo_l = mid
+        end
+    end
+    return best[1]                            # [(k_lo, k_hi)] 1-based inclusive, one per rank
+end
 
 function set_option!(ev::GPUEvaluator, name::AbstractString, value::Integer)
     v64 = Int64(value)

@@ -25,12 +25,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N=9):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        p = O.make_scaled_problem(9, 4, 2, seed=6, with_constraint=True)
+        p = O.make_scaled_problem(N, 4, 2, seed=6, with_constraint=True)
         ev_o = O.OracleEvaluator(p)
         Z = p.Z0
         mu = np.random.default_rng(1).standard_normal(ev_o.n_constraints)
@@ -99,12 +99,14 @@ def test_padded_gather_plan_shapes():
 import pytest
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_rank_shards_and_gather(world):
+@pytest.mark.parametrize("world,N", [(2, 9), (3, 9), (8, 16)])
+def test_two_rank_shards_and_gather(world, N):
+    """world 8 = the node the driver's scaling run uses: eight processes, two knots each, the padded in-place all-gather with eight
+    chunks, the broadcast form, the row segments and the objective all-reduce -- on CPU tensors over gloo."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

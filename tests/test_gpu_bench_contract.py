@@ -92,15 +92,16 @@ def test_asking_for_more_gpus_than_visible_fails_loudly():
 
 def test_a_hung_report_block_cannot_lose_the_headline():
     """The gather / strong-scaling reports run collectives after `value` has been measured; a watchdog bounds them.  With the
-    limit at zero every rank leaves at once and rank 0 prints the headline alone, marked as such."""
+    limit at zero every rank leaves at once and rank 0 prints the headline alone, marked `"status": "collective_timeout"` -- and the
+    process exits NON-ZERO: a hung collective must never read as a clean run to whoever launched the bench."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DTO_BENCH_WATCHDOG_S="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
                         "--n", "64", "--knots", "600", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.returncode != 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
     for k in REQUIRED[:-1]:
         assert k in d, k
-    assert d["n_gpus"] == 2 and "watchdog" in d and d["value"] > 0
+    assert d["n_gpus"] == 2 and "watchdog" in d and d["status"] == "collective_timeout" and d["value"] > 0
     assert abs(d["value"] - 1200 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

@@ -69,7 +69,7 @@ def test_every_ccall_names_an_entry_point_with_the_right_argument_count():
     for need in ("dto_eval_objective_dev", "dto_eval_gradient_dev", "dto_eval_constraint_dev", "dto_eval_jacobian_dev",
                  "dto_eval_hessian_dev", "dto_bind_output_dev", "dto_comm_unique_id", "dto_comm_create", "dto_comm_destroy", "dto_get_gather_layout",
                  "dto_gather_jacobian_dev", "dto_gather_hessian_dev", "dto_gather_gradient_dev", "dto_gather_constraint_dev",
-                 "dto_allreduce_objective_dev"):
+                 "dto_allreduce_objective_dev", "dto_interval_costs"):
         assert need in called, need
     for name, args, ret in calls:
         assert name in protos, name
