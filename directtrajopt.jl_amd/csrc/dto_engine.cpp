@@ -227,6 +227,9 @@ struct dto_handle {
     double* d_jac_scratch = nullptr;     // value slab for the Jacobian-vector products (lazy)
     double* d_w = nullptr;               // product input
     int64_t* d_conbase = nullptr;        // [n_vars+1] first constraint-pattern entry of each column
+    int64_t* d_crow_ptr = nullptr;       // the constraint pattern in row order (J w gathers rows): [rows+1], columns, slab positions
+    int64_t* d_crow_col = nullptr;
+    int64_t* d_crow_pos = nullptr;
     int64_t* d_con_rows = nullptr;       // constraint-pattern rows, (col,row) order
     double* h_pinned = nullptr;  // [32]: 0-1 bounds, 2-3 chain scalars, 6 sweep stats, 16-23 hump readback
     hipStream_t stream = nullptr;
@@ -554,6 +557,7 @@ Bounds get_bounds(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
 
 struct SweepPlan {
     int q, d_ub;
+    int tc = -1;   // first step at which the termination test runs (-1: d_ub / 2 - 1)
 };
 void read_hump(dto_handle* h, BilHost& b);
 SweepPlan plan_hump(const BilHost& b, double beta_fallback);
@@ -603,7 +607,7 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
     // upper bound on the terms needed at this very Z, so tc is a function of Z alone and results stay reproducible; a
     // column block that would pass earlier merely adds a few terms below 1e-16 of its sum).
     static const int tc_env = tune_int("DTO_SWEEP_TC", -1);
-    int tc = tc_env >= 0 ? tc_env : plan.d_ub / 2 - 1;
+    int tc = tc_env >= 0 ? tc_env : (plan.tc >= 0 ? plan.tc : plan.d_ub / 2 - 1);
     if (tc < 2) tc = 0;
     // Generator-stationary form (dto_sweep_gs.hip, round 4): clusters of npad / 32 workgroups with the generators resident in
     // their registers; serves what the single-workgroup form cannot fill the chip with -- single-column sweeps (eval_constraint,
@@ -877,7 +881,10 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             }
             launch_norm_from_colsum_multi(st, npad, nb, 3, css, w.norms);
         } else {
-            launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+            {
+                ProfScope ps(h, st, CAT_BUILD_A, 8.0 * npad * (double)npad * nb);
+                launch_build_A(st, h->P, b.k, dZ, int0, nb, w.W[0]);
+            }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[0], w.W[1]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[0], w.W[1], w.W[2]); }
             { ProfScope ps(h, st, CAT_BGEMM, gemm_flops * nb); launch_bgemm_plain(st, npad, nb, w.W[1], w.W[1], w.W[3]); }
@@ -1065,9 +1072,31 @@ SweepPlan plan_hump(const BilHost& b, double beta_fallback) {
     return plan_sweep(beta_fallback);
 }
 
-SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st) {
+// `loose`: the caller keeps no Taylor terms (eval_constraint without reuse_forward_sweep), so a generous step budget costs nothing --
+// the one-launch sweeps end by their own termination test.  Then the hump criterion is applied to the cheap bound itself
+// (max_k beta^k / k! <= e^9, the same four digits plan_hump allows): at the benchmark shape the triangle-inequality bound on
+// ||A^2||^(1/2) is 9.5, just past the beta <= 9 rule, and the exact norm (a store-less basis GEMM, a kernel for the hump and two
+// host round trips: 0.2 of the callback's 1.1 ms) was bought only to learn what this already shows.
+SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, bool loose = false) {
     Bounds bd = get_bounds(h, b, dZ, st);
     if (plan_sweep(bd.beta).q == 1) return plan_sweep(bd.beta);  // the cheap bound already gives one round
+    if (loose && bd.beta == bd.beta && bd.beta < 40.0) {
+        double lh = 0.0;
+        for (int k = 1; k < 200; ++k) lh = std::max(lh, k * std::log(bd.beta) - std::lgamma(k + 1.0));
+        if (lh <= 9.0) {
+            SweepPlan p{1, 12};
+            int t = 8;
+            double term = 1.0;
+            for (int i = 1; i <= t; ++i) term *= bd.beta / i;
+            while (term > 1e-19 && t < 200) { ++t; term *= bd.beta / t; }
+            p.d_ub = t + 6;
+            // the terms of the series grow up to index ~beta and fall from there: the test (two successive terms below 1.1e-16 of the
+            // sum, Al-Mohy & Higham's own criterion, which they apply from the first term on) starts a few terms past the peak
+            // of the BOUND -- a function of Z alone, like d_ub / 2 - 1, but not inflated by the bound's slack in the tail
+            p.tc = std::min(p.d_ub / 2 - 1, std::max(2, (int)std::ceil(bd.beta) + 4));
+            return p;
+        }
+    }
     double d2 = exact_d2(h, b, dZ, st);
     auto plan = [&] { return plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2); };
     if (d2 == d2 && plan().q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);  // ||A^3||, ||A^4|| sharpen the bound
@@ -1174,7 +1203,7 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
         }
         if (h->P.n_int > 0) {
             if (!(same && b.cache_kind >= 1)) {  // else exp(A)x of this very point is still in b.fw.S
-                SweepPlan plan = plan_from(h, b, dZ, st);
+                SweepPlan plan = plan_from(h, b, dZ, st, /*loose=*/!(h->reuse && b.pairing));
                 SweepTypes ty = make_types(0, false);
                 // with reuse on, the terms of the p column are kept: a Jacobian at this point then sweeps its tangent
                 // columns alone and a Hessian needs no forward sweep at all
@@ -2128,6 +2157,14 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             }
             c.k.n_times = (int64_t)times.size();
             c.k.mu_off = c.row_off;
+            {
+                std::vector<int64_t> st = times;
+                std::sort(st.begin(), st.end());
+                c.k.repeats = std::adjacent_find(st.begin(), st.end()) != st.end() ? 1 : 0;
+                std::vector<int32_t> sc = c.comps;
+                std::sort(sc.begin(), sc.end());
+                c.k.comp_repeats = std::adjacent_find(sc.begin(), sc.end()) != sc.end() ? 1 : 0;
+            }
             if (!sonly) {
                 c.k.comps = own(h, dupload(c.comps));
                 c.k.times = own(h, dupload(times));
@@ -2729,6 +2766,23 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
         for (int64_t c = 0; c < h->n_vars; ++c) base[(size_t)c + 1] += base[(size_t)c];
         h->d_conbase = own(h, dupload(base));
         h->d_con_rows = own(h, dupload(h->con_rows));
+        // the constraint entries once more in ROW order (J w gathers every row in ascending column order: no atomics): per
+        // constraint row the columns of its entries and their positions in the value slab
+        const int64_t n_con_rows = h->n_cons - h->n_dyn;
+        std::vector<int64_t> rptr((size_t)n_con_rows + 1, 0), rcol(h->con_rows.size()), rpos(h->con_rows.size());
+        for (size_t e = 0; e < h->con_rows.size(); ++e) rptr[(size_t)(h->con_rows[e] - h->n_dyn) + 1]++;
+        for (int64_t r = 0; r < n_con_rows; ++r) rptr[(size_t)r + 1] += rptr[(size_t)r];
+        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+        for (size_t e = 0; e < h->con_rows.size(); ++e) {   // CSC order: ascending column, so every row's list ends up ascending too
+            const int64_t col = h->con_cols[e], r = h->con_rows[e] - h->n_dyn;
+            const int64_t kn = col / h->z;
+            const int64_t at = fill[(size_t)r]++;
+            rcol[(size_t)at] = col;
+            rpos[(size_t)at] = h->colptr[col] + (int64_t)h->D * col_cnt(h, kn) + ((int64_t)e - base[(size_t)col]) - h->P.jac_lo;
+        }
+        h->d_crow_ptr = own(h, dupload(rptr));
+        h->d_crow_col = own(h, dupload(rcol));
+        h->d_crow_pos = own(h, dupload(rpos));
     }
     KIntegTable T{};
     T.n = (int)h->integ_kind.size();
@@ -2738,8 +2792,10 @@ static void jac_product(dto_handle* h, const double* Z, const double* w, double*
     do_jacobian(h, h->d_Z, h->d_jac_scratch, h->stream);
     double* o = staging(h, (size_t)n_out);
     HIP_CHECK(hipMemsetAsync(o, 0, sizeof(double) * (size_t)n_out, h->stream));  // fill!(y, 0), evaluator.jl:416,442
-    if (T.n > 0 || !h->con.empty())
-        launch_jac_spmv(h->stream, h->P, T, h->d_conbase, h->d_con_rows, h->d_jac_scratch, h->d_w, o, transpose, h->gd);
+    if (T.n > 0 || !h->con.empty()) {
+        if (transpose) launch_jac_spmv(h->stream, h->P, T, h->d_conbase, h->d_con_rows, h->d_jac_scratch, h->d_w, o, 1, h->gd);
+        else launch_jac_rowgather(h->stream, h->P, T, h->n_cons - h->n_dyn, h->d_crow_ptr, h->d_crow_col, h->d_crow_pos, h->n_dyn, h->d_jac_scratch, h->d_w, o);
+    }
     HIP_CHECK(hipMemcpyAsync(y, o, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
 }

@@ -314,6 +314,7 @@ struct KCon {  // NonlinearKnotPointConstraint with a built-in g
     const int32_t* hess_on;  // device, 0 where a LATER entry of `times` names the same knot: the reference's
                              // ForwardDiff.hessian! into the block view overwrites (knot_point_constraint.jl:285-291)
     int32_t g_dim, external; // outputs per listed time (1 for the built-in kinds); external: values come from the host
+    int32_t repeats, comp_repeats;  // the owned `times` name a knot twice / `comps` name a component twice (J' w then adds in listing order)
 };
 void launch_cons_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, double* g);
 void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* w, double* y, int transpose);
@@ -408,6 +409,9 @@ struct KIntegTable {
 };
 void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
                      const double* vals, const double* w, double* y, int transpose, int64_t global_cols = 0);
+// y = J w from the value slab row by row (fixed summation order; the transpose takes launch_jac_spmv, one wavefront per column)
+void launch_jac_rowgather(hipStream_t st, const KProb& P, const KIntegTable& T, int64_t n_con_rows, const int64_t* rptr, const int64_t* rcol,
+                          const int64_t* rpos, int64_t n_dyn, const double* vals, const double* w, double* y);
 void launch_add(hipStream_t st, double* dst, const double* src, int64_t n);  // dst += src
 // *flag = 0 if a and b differ in any bit (flag preset to 1 by the caller)
 void launch_bits_equal(hipStream_t st, const double* a, const double* b, int64_t n, int32_t* flag);

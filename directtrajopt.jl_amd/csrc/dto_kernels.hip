@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64) k_jac_spmv(KProb P, KIntegTable T, const i
     const int cnt = has_prev + has_own;
     const int64_t e0 = P.colptr[c], e1 = P.colptr[c + 1];
     const int64_t Lint = (int64_t)P.D * cnt;
-    const double wc = TRANSPOSE ? 0.0 : w[c];
+    static_assert(TRANSPOSE == 1, "J w takes the row gather (launch_jac_rowgather): a column walk would meet other columns in y[row]");
     double acc = 0.0;
     for (int64_t e = e0 + threadIdx.x; e < e1; e += 64) {
         const int64_t el = e - e0;
@@ -404,20 +404,51 @@ __global__ void __launch_bounds__(64) k_jac_spmv(KProb P, KIntegTable T, const i
             row = con_rows[conbase[c] + (el - Lint)];
         }
         const double v = vals[e - P.jac_lo];
-        if (TRANSPOSE) acc += v * w[row];
-        else if (v != 0.0) atomicAdd(&y[row], v * wc);
+        acc += v * w[row];
     }
-    if (TRANSPOSE) {
-        acc = wave_sum(acc);
-        if (threadIdx.x == 0) y[c] = acc;
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) y[c] = acc;
+}
+// y = J w from the value slab ROW BY ROW (no atomics: the order of every row's sum is fixed).  An integrator row (integrator i,
+// interval k, r) has its 2z entries at closed-form positions: part 1 of the columns of knot k, part 0 of those of knot k + 1; one
+// wavefront per row takes them in ascending column order per lane and a fixed shuffle tree.
+__global__ void __launch_bounds__(64) k_jac_rowgather_integ(KProb P, KIntegTable T, const double* __restrict__ vals,
+                                                            const double* __restrict__ w, double* __restrict__ y) {
+    const int64_t R = blockIdx.x;
+    int i = 0, pre = 0;
+    while (i < T.n - 1 && R >= T.off[i] + (int64_t)T.d[i] * P.K) { pre += T.d[i]; ++i; }
+    const int d = T.d[i];
+    const int64_t kn = (R - T.off[i]) / d;
+    const int r = (int)((R - T.off[i]) % d);
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < P.z; j += 64) {
+        acc += vals[jac_pos(P, P.colptr, kn, j, pre, d, 1, r)] * w[kn * P.z + j];
+        acc += vals[jac_pos(P, P.colptr, kn + 1, j, pre, d, 0, r)] * w[(kn + 1) * P.z + j];
     }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) y[R] = acc;
+}
+// ... a constraint row takes its entries from the row-ordered copy of the constraint pattern (ascending column)
+__global__ void __launch_bounds__(64) k_jac_rowgather_con(const int64_t* __restrict__ rptr, const int64_t* __restrict__ rcol,
+                                                          const int64_t* __restrict__ rpos, int64_t row0, const double* __restrict__ vals,
+                                                          const double* __restrict__ w, double* __restrict__ y) {
+    const int64_t r = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t e = rptr[r] + threadIdx.x; e < rptr[r + 1]; e += 64) acc += vals[rpos[e]] * w[rcol[e]];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) y[row0 + r] = acc;
+}
+void launch_jac_rowgather(hipStream_t st, const KProb& P, const KIntegTable& T, int64_t n_con_rows, const int64_t* rptr, const int64_t* rcol,
+                          const int64_t* rpos, int64_t n_dyn, const double* vals, const double* w, double* y) {
+    if (T.n > 0 && n_dyn > 0) hipLaunchKernelGGL(k_jac_rowgather_integ, dim3((unsigned)n_dyn), dim3(64), 0, st, P, T, vals, w, y);
+    if (n_con_rows > 0) hipLaunchKernelGGL(k_jac_rowgather_con, dim3((unsigned)n_con_rows), dim3(64), 0, st, rptr, rcol, rpos, n_dyn, vals, w, y);
 }
 void launch_jac_spmv(hipStream_t st, const KProb& P, const KIntegTable& T, const int64_t* conbase, const int64_t* con_rows,
                      const double* vals, const double* w, double* y, int transpose, int64_t global_cols) {
     const int64_t ncols = P.n_knots * P.z + global_cols;
     if (ncols <= 0) return;
-    if (transpose) hipLaunchKernelGGL(k_jac_spmv<1>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
-    else hipLaunchKernelGGL(k_jac_spmv<0>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
+    (void)transpose;  // J' w only: one wavefront per column; J w is launch_jac_rowgather
+    hipLaunchKernelGGL(k_jac_spmv<1>, dim3((unsigned)ncols), dim3(64), 0, st, P, T, conbase, con_rows, vals, w, y);
 }
 
 // Zero-fill of the Jacobian slab (fill!(∂, 0), evaluator.jl:497) that skips the -E_k block of one bilinear
@@ -1950,7 +1981,7 @@ __global__ void __launch_bounds__(256) k_jtv_bilinear(KProb P, KBil B, SweepBuf 
         double v = 0.0;
         if (own) v -= ad.S[col + r];                                   // -exp(A_k)' w_k
         if (kn >= 1) v += w[B.row_off + (kn - 1) * n + r];             // +I' w_{k-1}
-        atomicAdd(&yk[B.x_off + r], v);
+        yk[B.x_off + r] += v;   // (every entry of y has ONE writer per launch, launches follow each other on the stream: fixed order)
     }
     if (!own) return;
     const double* wk = w + B.row_off + kn * n;
@@ -1960,7 +1991,7 @@ __global__ void __launch_bounds__(256) k_jtv_bilinear(KProb P, KBil B, SweepBuf 
         for (int r = threadIdx.x; r < n; r += 256) s += c[r] * wk[r];
         s = block_sum_256(s, sm);
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&yk[j < B.m ? B.u_off + j : P.dt_idx], -s);
+        if (threadIdx.x == 0) yk[j < B.m ? B.u_off + j : P.dt_idx] -= s;
     }
 }
 void launch_jtv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& fw, const SweepBuf& ad, const double* w, double* y) {
@@ -1968,9 +1999,8 @@ void launch_jtv_bilinear(hipStream_t st, const KProb& P, const KBil& B, const Sw
     hipLaunchKernelGGL(k_jtv_bilinear, dim3((unsigned)P.n_knots), dim3(256), 0, st, P, B, fw, ad, w, y);
 }
 
-// DerivativeIntegrator rows: -w_x - dt w_xdot - xdot w_dt + w_x(k+1)   and the transpose
-__global__ void k_jv_derivative(KProb P, KDer D, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y,
-                                int transpose) {
+// DerivativeIntegrator rows: -w_x - dt w_xdot - xdot w_dt + w_x(k+1)
+__global__ void k_jv_derivative(KProb P, KDer D, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n_int * D.d) return;
     const int64_t kl = i / D.d;
@@ -1978,28 +2008,68 @@ __global__ void k_jv_derivative(KProb P, KDer D, const double* __restrict__ Z, c
     const int64_t kn = P.kn_lo + kl;
     const double* zk = Z + kn * P.z;
     const int64_t row = D.row_off + kn * D.d + r;
-    if (!transpose) {
-        const double* wk = w + kn * P.z;
-        y[row] = -wk[D.x_off + r] - zk[P.dt_idx] * wk[D.xdot_off + r] - zk[D.xdot_off + r] * wk[P.dt_idx] + wk[P.z + D.x_off + r];
-    } else {
-        const double wr = w[row];
-        double* yk = y + kn * P.z;
-        atomicAdd(&yk[D.x_off + r], -wr);
-        atomicAdd(&yk[D.xdot_off + r], -zk[P.dt_idx] * wr);
-        atomicAdd(&yk[P.dt_idx], -zk[D.xdot_off + r] * wr);
-        atomicAdd(&yk[P.z + D.x_off + r], wr);
+    const double* wk = w + kn * P.z;
+    y[row] = -wk[D.x_off + r] - zk[P.dt_idx] * wk[D.xdot_off + r] - zk[D.xdot_off + r] * wk[P.dt_idx] + wk[P.z + D.x_off + r];
+}
+// ... and the transpose: one workgroup per knot, every entry of y with ONE writer per phase, the phases (x entries: own interval
+// and the +I of the interval before; xdot entries; the timestep entry, a block sum in a fixed tree) separated by barriers so that
+// components that coincide (x and xdot overlapping, the timestep inside one of them) still add in a fixed order -- no atomics.
+__global__ void __launch_bounds__(256) k_jtv_derivative(KProb P, KDer D, const double* __restrict__ Z, const double* __restrict__ w,
+                                                         double* __restrict__ y) {
+    __shared__ double sm[4];
+    const int64_t kl = blockIdx.x;
+    const int64_t kn = P.kn_lo + kl;
+    const bool own = kn < P.K && kl < P.n_int;
+    const double* zk = Z + kn * P.z;
+    double* yk = y + kn * P.z;
+    const double* wk = w + D.row_off + kn * D.d;          // rows of interval kn
+    for (int r = threadIdx.x; r < D.d; r += 256) {
+        double v = 0.0;
+        if (own) v -= wk[r];
+        if (kn >= 1) v += w[D.row_off + (kn - 1) * D.d + r];
+        yk[D.x_off + r] += v;
     }
+    if (!own) return;
+    __syncthreads();
+    for (int r = threadIdx.x; r < D.d; r += 256) yk[D.xdot_off + r] -= zk[P.dt_idx] * wk[r];
+    __syncthreads();
+    double s = 0.0;
+    for (int r = threadIdx.x; r < D.d; r += 256) s += zk[D.xdot_off + r] * wk[r];
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) yk[P.dt_idx] -= s;
 }
 void launch_jv_derivative(hipStream_t st, const KProb& P, const KDer& D, const double* dZ, const double* w, double* y, int transpose) {
-    const int64_t n = P.n_int * D.d;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_jv_derivative, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, D, dZ, w, y, transpose);
+    if (!transpose) {
+        const int64_t n = P.n_int * D.d;
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_jv_derivative, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, D, dZ, w, y);
+    } else {
+        if (P.n_knots <= 0) return;
+        hipLaunchKernelGGL(k_jtv_derivative, dim3((unsigned)P.n_knots), dim3(256), 0, st, P, D, dZ, w, y);
+    }
 }
 
 // knot constraints: only entries inside the pattern taken at Z0 take part (evaluator.jl:545-547)
-__global__ void k_jv_knot(KProb P, KCon C, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y, int transpose) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C.n_times * C.n_comps) return;
+// J w: one thread per listed time sums its row over the components in order (rows of different listings are different rows).
+// J' w: entry (knot, component) is written by the thread of (listing, component); listings that repeat a knot would meet in one
+// entry, so a constraint whose `times` repeat a knot runs the serial form (one workgroup walks the listings in order).
+__global__ void k_jv_knot(KProb P, KCon C, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y) {
+    const int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= C.n_times) return;
+    const int64_t kn = C.times[ti];
+    const double* zk = Z + kn * P.z;
+    const double nrm = C.kind == 1 ? sqrt(knot_norm2(P, C, zk)) : 1.0;
+    double s = 0.0;
+    bool any = false;
+    for (int c = 0; c < C.n_comps; ++c) {
+        if (C.jpos[ti * C.n_comps + c] < 0) continue;
+        const double v = zk[C.comps[c]];
+        s += (C.kind == 1 ? v / nrm : 2.0 * v) * w[kn * P.z + C.comps[c]];
+        any = true;
+    }
+    if (any) y[C.mu_off + C.tidx[ti]] += s;
+}
+__device__ __forceinline__ void jtv_knot_one(const KProb& P, const KCon& C, const double* Z, const double* w, double* y, int64_t i) {
     if (C.jpos[i] < 0) return;
     const int64_t ti = i / C.n_comps;
     const int c = (int)(i % C.n_comps);
@@ -2007,14 +2077,33 @@ __global__ void k_jv_knot(KProb P, KCon C, const double* __restrict__ Z, const d
     const double* zk = Z + kn * P.z;
     const double v = zk[C.comps[c]];
     const double jac = C.kind == 1 ? v / sqrt(knot_norm2(P, C, zk)) : 2.0 * v;
-    const int64_t row = C.mu_off + C.tidx[ti], colg = kn * P.z + C.comps[c];
-    if (!transpose) atomicAdd(&y[row], jac * w[colg]);
-    else atomicAdd(&y[colg], jac * w[row]);
+    y[kn * P.z + C.comps[c]] += jac * w[C.mu_off + C.tidx[ti]];
+}
+// serial = 0: one thread per (listing, component); 1: thread c walks component c through the listings in order; 2: one thread all
+__global__ void k_jtv_knot(KProb P, KCon C, const double* __restrict__ Z, const double* __restrict__ w, double* __restrict__ y, int serial) {
+    const int64_t n = C.n_times * C.n_comps;
+    if (serial == 0) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n) jtv_knot_one(P, C, Z, w, y, i);
+    } else if (serial == 1) {
+        for (int c = threadIdx.x; c < C.n_comps; c += blockDim.x)
+            for (int64_t ti = 0; ti < C.n_times; ++ti) jtv_knot_one(P, C, Z, w, y, ti * C.n_comps + c);
+    } else if (threadIdx.x == 0) {
+        for (int64_t i = 0; i < n; ++i) jtv_knot_one(P, C, Z, w, y, i);
+    }
 }
 void launch_jv_knot(hipStream_t st, const KProb& P, const KCon& C, const double* dZ, const double* w, double* y, int transpose) {
     const int64_t n = C.n_times * C.n_comps;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_jv_knot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, C, dZ, w, y, transpose);
+    if (!transpose) {
+        hipLaunchKernelGGL(k_jv_knot, dim3((unsigned)((C.n_times + 255) / 256)), dim3(256), 0, st, P, C, dZ, w, y);
+    } else if (C.repeats || C.comp_repeats) {
+        // listings that repeat a knot meet in one entry: the listings are then walked in order (components of one listing are
+        // different entries unless a component is listed twice: then one thread walks everything)
+        hipLaunchKernelGGL(k_jtv_knot, dim3(1), dim3(64), 0, st, P, C, dZ, w, y, C.comp_repeats ? 2 : 1);
+    } else {
+        hipLaunchKernelGGL(k_jtv_knot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, C, dZ, w, y, 0);
+    }
 }
 
 // ============================================================================================

@@ -364,8 +364,8 @@ int dto_bind_output_dev(dto_handle* h, int32_t vector, double* dptr);
  *   host-pointer dto_eval_jacobian runs the propagator chain in the same chunks as dto_eval_jacobian_dev (else the early
  *   hand-over of -E_k caps the chunk, and the evaluation form is decided per chunk).  Cost at 256 x 2000: +0.1..0.4 ms per
  *   device-resident Jacobian, and the host-pointer Jacobian loses the overlap of its PCIe copy with the chain (23 -> 34 ms).
- *   Not covered: dto_eval_jacobian_product / _transpose_product (floating-point atomics over rows shared by several
- *   integrators). */
+ *   dto_eval_jacobian_product / _transpose_product are covered since round 4: every entry of y has one writer per launch with a
+ *   fixed internal order (J w gathers row by row; J' w writes per knot, listings that repeat a knot in listing order). */
 int dto_set_option(dto_handle* h, const char* name, int64_t value);
 
 /* measurement hooks: HIP-event timing of the engine's kernels on the stream they are launched on */

@@ -45,6 +45,49 @@ def test_single_gpu_line():
     assert si["finite"] is True and si["ms_per_iteration"] > 0 and si["ms_per_iteration_reuse_forward_sweep"] > 0, si
     if "roofline" in hr:   # (64 states x 1200 knots: the adjoint sweep runs in the fused or the cluster form, both timed)
         assert hr["roofline"]["bound"] == "mfma" and 0 < hr["roofline"]["frac"] < 1
+    # round 4: the bandwidth-bound assembly kernels against the HBM roof, the PCIe-inclusive figures and SURVEY 8d's literal metric
+    ah = d["assembly_hbm"]
+    for k in ("zero_fill", "build_A"):    # (basis_multi exists from 128 states on: 64 states take the three-GEMM power chain)
+        assert ah[k]["unit"] == "GB/s" and ah[k]["achieved"] > 0 and 0 < ah[k]["frac"] < 1.2 and ah[k]["algorithmic_bytes_per_launch"] > 0, (k, ah[k])
+    hp = d["host_pointer"]
+    assert hp["eval_constraint_jacobian"]["ms_per_call_median"] > 0 and hp["eval_hessian_lagrangian"]["ms_per_call_median"] > 0, hp
+    vh = d["value_incl_h2d_median"]
+    assert vh["value"] > 0 and vh["ms_per_step_median"] >= 0.9 * d["ms_per_step_median"]
+    # the per-instance HBM figures exist for every shape, not only the headline's
+    assert rf["template_instances"]["horner"]["algorithmic_hbm_bytes"] == 7 * 8.0 * 64 * 64 * 1199
+
+
+@pytest.mark.parametrize("callback", ["hessian", "constraint"])
+def test_other_callbacks_have_a_roofline_line_of_their_own(callback):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n", "256", "--knots", "300",
+                        "--callback", callback, "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    rf = d["roofline"]
+    assert callback in d["metric"] and rf["bound"] == "mfma" and rf["launches"] > 0 and 0 < rf["frac"] < 1, rf
+    assert d["callback_hbm"]["algorithmic_bytes"] > 0 and d["config"]["outputs_finite"] is True
+
+
+def test_four_rank_rehearsal_on_one_device():
+    """The widest multi-rank rehearsal a one-GPU box allows (its process guard admits six processes with the GPU open: this test's
+    own process, the launcher and four ranks -- five ranks were killed by it): four ranks, each with an engine handle on its shard
+    plus the two sub-handles of the overlapped gather, four RCCL communicators over loopback, the in-place all-gather with four
+    chunks and the strong split -- what `--gpus 8` runs on a node, at half the width.  World 8 itself is covered on the CPU: tests/test_comm_layout.py (layouts of configs[3] / configs[4] over
+    eight ranks) and tests/test_distributed_gloo.py (eight gloo processes)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--one-device",
+                        "--n", "64", "--knots", "200", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 4 and d["config"]["knots_total"] == 800 and "status" not in d
+    g = d["gather"]
+    assert "error" not in g and "overlapped_error" not in g, g
+    assert g["n_ranks"] == 4 and g["sampled_finite"] is True and "ncclAllGather" in g["collective"]
+    assert g["overlapped_vs_sequential_max_rel_diff_sampled"] <= 1e-10
+    st = d["strong_scaling"]
+    assert st["knots_total"] == 200 and st["knots_per_gpu"] == 50 and st["outputs_finite"]
 
 
 def test_gpus_2_without_torchrun_starts_two_ranks_itself():

@@ -19,7 +19,20 @@ def _five(ev, Z, mu, sigma=0.7):
     c = np.empty(ev.shard.cons_len); ev.eval_constraint(c, Z); out["cons"] = c
     j = np.empty(ev.shard.jac_len); ev.eval_constraint_jacobian(j, Z); out["jac"] = j
     h = np.empty(ev.shard.hess_len); ev.eval_hessian_lagrangian(h, Z, sigma, mu); out["hess"] = h
+    # J w and J' w (evaluator.jl:406-456): matrix-free on the general path, from the materialised slab on the small-state path and
+    # with host-evaluated terms -- one writer per entry and fixed orders in both since round 4
+    w = np.cos(np.arange(ev.n_variables) * 0.37)
+    y = np.empty(ev.n_constraints); ev.eval_constraint_jacobian_product(y, Z, w); out["Jw"] = y
+    yt = np.empty(ev.n_variables); ev.eval_constraint_jacobian_transpose_product(yt, Z, mu); out["JTw"] = yt
     return out
+
+
+def _dup_constraint_problem():
+    """A knot constraint whose `times` name knots twice (J' w: both listings add into the same entries of y, in listing order)."""
+    p = O.make_scaled_problem(10, 40, 3, seed=23, with_constraint=True)
+    c = p.constraints[0]
+    p.constraints = [O.KnotConstraint(c.kind, c.comps, c.c, [2, 3, 3, 5, 2, 9], equality=c.equality)]
+    return p
 
 
 def _dup_problem():
@@ -34,10 +47,10 @@ def _dup_problem():
     return p
 
 
-@pytest.mark.parametrize("make", [lambda: O.make_scaled_problem(12, 40, 3, seed=21, with_constraint=True), _dup_problem,
+@pytest.mark.parametrize("make", [lambda: O.make_scaled_problem(12, 40, 3, seed=21, with_constraint=True), _dup_problem, _dup_constraint_problem,
                                   lambda: O.make_global_problem(), lambda: O.make_scaled_problem(40, 130, 2, seed=2),
                                   lambda: O.make_standard_problem(N=10)],
-                         ids=["general-path", "repeated-knots", "global-terms", "fused-sweep-128", "small-state-path"])
+                         ids=["general-path", "repeated-knots", "repeated-constraint-knots", "global-terms", "fused-sweep-128", "small-state-path"])
 def test_repeated_calls_return_the_same_bits(make):
     import dto_amd
     p = make()
@@ -52,6 +65,11 @@ def test_repeated_calls_return_the_same_bits(make):
         assert rel_err(first["jac"], ev_o.eval_constraint_jacobian(Z)) <= 1e-10
         assert rel_err(first["grad"], ev_o.eval_objective_gradient(Z)) <= 1e-10
         assert rel_err(first["hess"], ev_o.eval_hessian_lagrangian(Z, 0.7, mu)) <= 1e-8
+        r1, c1 = ev_o.jacobian_structure1()
+        import scipy.sparse as sp
+        J = sp.csr_matrix((ev_o.eval_constraint_jacobian(Z), (r1 - 1, c1 - 1)), shape=(ev_o.n_constraints, p.n_vars))
+        assert rel_err(first["Jw"], J @ np.cos(np.arange(p.n_vars) * 0.37)) <= 1e-10
+        assert rel_err(first["JTw"], J.T @ mu) <= 1e-10
         # ... and every repetition reproduces them exactly, also with other points evaluated in between
         for rep in range(4):
             if rep == 2:

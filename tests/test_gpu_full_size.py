@@ -324,3 +324,99 @@ def test_config4_workload_1024_states_64_knots_sampled():
         ref = ev_o.eval_constraint(sub.Z0)
         assert rel_err(cons[k * n:(k + 1) * n], ref[:n]) <= 1e-10
     ev.close()
+
+
+def test_config4_per_rank_share_1024_states_500_knots_of_4000():
+    """BASELINE configs[4] as ONE of its eight ranks runs it: the 4000-knot problem (1024 states, ||u|| - 1 <= 0, L1 slack), the
+    handle owning knots 1501..2000 -- 500 knots, the per-GPU share -- with every output resident in HBM (8.5 GB of Jacobian
+    values, 6.4 GB of Hessian values).  Sampled knots of the shard against two-knot oracle problems: bilinear and derivative
+    defects, Jacobian column blocks cut by the GLOBAL column pointers minus the shard's offset, the constraint rows and their
+    Jacobian entries against the closed form, one Hessian diagonal block ((u, u) entries left to the three-knot test above)."""
+    import torch
+    import dto_amd
+    n, m, N, world, rank = 1024, 4, 4000, 8, 3
+    prob = dto_amd.host.synthetic.make_l1_slack_problem(N, n, m)
+    lo, hi = dto_amd.distributed.shard_ranges(N, world)[rank]
+    assert (lo, hi) == (1501, 2000)
+    ev = dto_amd.Evaluator(prob, k_lo=lo, k_hi=hi)
+    sh = ev.shard
+    z = prob.trajectory.dim
+    K, D = N - 1, n + m
+    dev = torch.device("cuda", 0)
+    Z = prob.trajectory.vec()
+    dZ = torch.from_numpy(Z).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    mu = np.random.default_rng(8).standard_normal(ev.n_constraints)
+    dmu = torch.from_numpy(mu).to(dev)
+    dj = torch.empty(sh.jac_len, dtype=torch.float64, device=dev)
+    dg = torch.empty(sh.cons_len, dtype=torch.float64, device=dev)
+    ev.eval_jacobian_dev(dZ.data_ptr(), dj.data_ptr(), st)
+    ev.eval_constraint_dev(dZ.data_ptr(), dg.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dj).all()) and bool(torch.isfinite(dg).all())
+    cons = dg.cpu().numpy()
+    X = prob.trajectory.data
+    U = X[n:n + m]
+    n_knots = hi - lo + 1
+    n_int = n_knots                                    # every owned knot of an interior rank owns an interval
+    assert sh.cons_len == n_int * D + n_knots          # dynamics rows of the owned intervals + one norm row per owned knot
+    k0 = lo - 1                                        # first owned knot, 0-based
+    nrm = np.linalg.norm(U[:, k0:k0 + n_knots], axis=0)
+    assert rel_err(cons[n_int * D:], nrm - 1.0) <= 1e-10
+    # global column pointers of the reference's CSC order: per column cnt * D integrator rows + the constraint row of u columns
+    cnt = np.full(N, 2); cnt[0] = 1; cnt[-1] = 1
+    per = np.repeat(cnt * D, z).astype(np.int64)
+    extra = np.zeros(N * z, dtype=np.int64)
+    for kn in range(1, N - 1):
+        extra[kn * z + n:kn * z + n + m] = 1
+    colptr = np.zeros(N * z + 1, dtype=np.int64)
+    colptr[1:] = np.cumsum(per + extra)
+    assert colptr[-1] == ev.n_jacobian_entries and colptr[k0 * z] == sh.jac_lo and colptr[(k0 + n_knots) * z] == sh.jac_lo + sh.jac_len
+    col = lambda c: dj[colptr[c] - sh.jac_lo:colptr[c + 1] - sh.jac_lo].cpu().numpy()
+    for kn in (k0, k0 + 1, k0 + 250, k0 + n_knots - 1):
+        for j in range(m):
+            assert rel_err(col(kn * z + n + j)[-1], U[j, kn] / nrm[kn - k0]) <= 1e-10   # d(||u|| - 1)/du_j, last in its column
+    G = prob.integrators[0].G
+    lin = [O.LinearRegularizer(n + 2 * m, m, np.full(m, 1e-2))]
+    for k in (k0, k0 + 251, k0 + n_knots - 1):
+        sub = _sub_problem(G, X[:, k:k + 2].T, n, m, z, n + 3 * m, lin)
+        ev_o = O.OracleEvaluator(sub)
+        r1, c1 = ev_o.jacobian_structure1()
+        sub_jac = _dense(r1, c1, ev_o.eval_constraint_jacobian(sub.Z0), (D, 2 * z))
+        for j in list(range(0, n, 131)) + list(range(n, z)):
+            cj = col(k * z + j)
+            own_b = cj[n:2 * n]                        # rows of interval k-1 come first (every sampled knot has one)
+            assert rel_err(own_b, sub_jac[:n, j]) <= 1e-10, (k, j)
+            own_d = cj[2 * n + m:2 * n + 2 * m]
+            assert rel_err(own_d, sub_jac[n:, j]) <= 1e-10, (k, j)
+        ref = ev_o.eval_constraint(sub.Z0)
+        kl = k - k0
+        assert rel_err(cons[kl * n:(kl + 1) * n], ref[:n]) <= 1e-10
+        assert rel_err(cons[n_int * n + kl * m:n_int * n + (kl + 1) * m], ref[n:]) <= 1e-10
+    del dj
+    # Hessian of the shard: one diagonal block against the oracle (mu of the interval's rows; the norm constraint of knot k adds
+    # its own (u, u) block, which lies among the entries left out)
+    dh = torch.empty(sh.hess_len, dtype=torch.float64, device=dev)
+    ev.eval_hessian_dev(dZ.data_ptr(), 0.8, dmu.data_ptr(), dh.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dh).all())
+    tri = z * (z + 1) // 2
+    k = k0 + 123
+    start = tri + (k - 1) * (z * z + tri) - sh.hess_lo     # column block of knot k: per column b the z off-diagonal rows, then b + 1
+    blkv = dh[start:start + z * z + tri].cpu().numpy()
+    Hd = np.zeros((z, z))
+    pos = 0
+    for b in range(z):
+        pos += z
+        Hd[:b + 1, b] = blkv[pos:pos + b + 1]
+        pos += b + 1
+    sub = _sub_problem(G, X[:, k:k + 2].T, n, m, z, n + 3 * m, lin)
+    ev_o = O.OracleEvaluator(sub)
+    mu_sub = np.concatenate([mu[k * n:(k + 1) * n], mu[K * n + k * m:K * n + (k + 1) * m]])
+    r1, c1 = ev_o.hessian_structure1()
+    Hs = _dense(r1, c1, ev_o.eval_hessian_lagrangian(sub.Z0, 0.8, mu_sub, skip_uu=True), (2 * z, 2 * z))[:z, :z]
+    keep = np.ones((z, z), dtype=bool)
+    keep[n:n + m, n:n + m] = False
+    assert rel_err(Hd[keep], Hs[keep]) <= 1e-8, rel_err(Hd[keep], Hs[keep])
+    assert np.all(Hd[:n, :n] == 0.0)
+    ev.close()
