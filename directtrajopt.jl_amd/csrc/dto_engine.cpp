@@ -1203,7 +1203,8 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
         }
         if (h->P.n_int > 0) {
             if (!(same && b.cache_kind >= 1)) {  // else exp(A)x of this very point is still in b.fw.S
-                SweepPlan plan = plan_from(h, b, dZ, st, /*loose=*/!(h->reuse && b.pairing));
+                SweepPlan plan = plan_from(h, b, dZ, st, /*loose=*/true);
+                if (plan.tc >= 0 && h->reuse && b.pairing && plan.d_ub + 1 > b.fw.dcap) plan = plan_from(h, b, dZ, st);  // the term store is what limits
                 SweepTypes ty = make_types(0, false);
                 // with reuse on, the terms of the p column are kept: a Jacobian at this point then sweeps its tangent
                 // columns alone and a Hessian needs no forward sweep at all
@@ -1351,7 +1352,10 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 HIP_CHECK(launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, true), make_types(b.k.m, false), dZ, dmu, nullptr, nullptr, dH, 4));
                 continue;
             }
-            SweepPlan plan = plan_from(h, b, dZ, st);
+            // (the budget from the cheap bound serves while the term store holds it: the sweeps end by their own test, and the
+            // pairing loops run over the terms actually produced -- the exact norms cost a store-less basis GEMM and two round trips)
+            SweepPlan plan = plan_from(h, b, dZ, st, /*loose=*/b.pairing);
+            if (plan.tc >= 0 && plan.d_ub + 1 > b.fw.dcap) plan = plan_from(h, b, dZ, st);
             const bool pair = b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
             const int m = b.k.m, T1 = 1 + m;
             int steps_f, Tf = T1;  // Tf: types per stored forward term

@@ -152,6 +152,11 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
         for (int u = 0; u < KW; ++u) {
             if (g <= m) af[g][u] = *reinterpret_cast<const d2*>(a.G + (int64_t)g * nn + (int64_t)(4 * (wave * KW + u) + lq) * NPAD + row0 + 2 * lr);
             else af[g][u] = d2{0.0, 0.0};
+            // the fragment must STAY in a register: an opaque pass keeps the compiler from re-loading it from memory inside the loop
+            // when registers get tight (it did, in a build whose loop it had left partly rolled: 176 global loads per item)
+            double fx = af[g][u].x, fy = af[g][u].y;
+            asm volatile("" : "+v"(fx), "+v"(fy));
+            af[g][u] = d2{fx, fy};
         }
 
     // ---- B operand of this lane: column 16 tj + lr of the group, rows 4 (wave KW + u) + lq of the term columns; padding
@@ -421,79 +426,78 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
 #pragma unroll
             for (int tj = 0; tj < NT; ++tj) acc[rt][tj] = d4{0.0, 0.0, 0.0, 0.0};
         GS_MARK(2);
-#pragma unroll
-        for (int g = 0; g < MP; ++g) {
-            if (NCH > 1 && g == GROT && prefetch && nx_t < a.d_ub) land_chunk(nx_grp, nx_t, 0, slot ^ 1);   // issued GROT generator blocks ago
-            double cA[NT], cB[NT];
-            int so[NT];
+        // The k-steps of all generators form ONE list of batches (GS_BK k-steps each).  The scaled B fragments of a batch are formed in
+        // one go: FP64 vector and matrix instructions share a pipe on this part, and with one wave per SIMD every switch between them
+        // is a bubble of a VALU latency (measured: ~27 cycles per VALU operation when each k-step scales its own fragment).  The raw
+        // term values of the NEXT batch are read from LDS before a batch's MFMAs, and the coefficients of the NEXT generator at the
+        // first batch of the current one: no dependent LDS chain stands at a generator boundary.
+        constexpr int BK = GS_BK < KW ? GS_BK : KW, NB = KW / BK;
+        double cA[NT], cB[NT], cAn[NT], cBn[NT], zr1[BK][NT], zr2[BK][NT];
+        int so[NT], son[NT];
+        auto coef = [&](int g, double (&xA)[NT], double (&xB)[NT], int (&xs)[NT]) {
 #pragma unroll
             for (int tj = 0; tj < NT; ++tj) {
                 const int cc = bok[tj] ? 16 * tj + lr : NC - 1;
-                cA[tj] = bok[tj] ? cgt[g * cap + cbase + bin[tj]] : 0.0;
-                cB[tj] = 0.0;
-                so[tj] = bcol[tj];
+                xA[tj] = bok[tj] ? cgt[g * cap + cbase + bin[tj]] : 0.0;
+                xB[tj] = 0.0;
+                xs[tj] = bcol[tj];
                 if (HAS_SRC) {
-                    cB[tj] = bok[tj] ? cgt[MP * cap + cbase + bin[tj]] * gcm[g * NCP + cc] : 0.0;
-                    so[tj] = gcs[g * NCP + cc] * ZS + lq + 4 * wave * KW;
+                    xB[tj] = bok[tj] ? cgt[MP * cap + cbase + bin[tj]] * gcm[g * NCP + cc] : 0.0;
+                    xs[tj] = gcs[g * NCP + cc] * ZS + lq + 4 * wave * KW;
                 }
             }
-            if (NCH > 1 && g == GROT && prefetch && nx_t < a.d_ub) issue_chunk(nx_grp, nx_t, 1);
-#if defined(GS_PROBE_NOLDS)   // timing probes (tools/sweep_gs_probe -D...; wrong results): what the loop costs without one of its parts
-#pragma unroll
-            for (int u = 0; u < KW; ++u) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int tj = 0; tj < NT; ++tj)
-                        acc[rt][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(cA[tj], rt ? af[g][u].y : af[g][u].x, acc[rt][tj], 0, 0, 0);
-            }
-#else
-            // The scaled B fragments are formed GS_BK k-steps at a time: FP64 vector and matrix instructions share a pipe on this
-            // part, and with one wave per SIMD every switch between them is a bubble of a VALU latency (measured: ~27 cycles per VALU
-            // operation when each k-step scales its own fragment) -- one batch of independent operations per GS_BK k-steps pays it once.
-            // The raw term values of the NEXT batch are read from LDS before the batch's MFMAs.
-            constexpr int BK = GS_BK < KW ? GS_BK : KW;
-            double zr1[BK][NT], zr2[BK][NT];
+        };
+        auto read_raw = [&](int u0, const int (&xs)[NT]) {
 #pragma unroll
             for (int b = 0; b < BK; ++b)
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj) {
-                    zr1[b][tj] = Zs[bcol[tj] + 4 * b];
-                    if (HAS_SRC) zr2[b][tj] = Zs[so[tj] + 4 * b];
+                    zr1[b][tj] = Zs[bcol[tj] + 4 * (u0 + b)];
+                    if (HAS_SRC) zr2[b][tj] = Zs[xs[tj] + 4 * (u0 + b)];
                 }
+        };
+        coef(0, cA, cB, so);
+        read_raw(0, so);
 #pragma unroll
-            for (int u0 = 0; u0 < KW; u0 += BK) {
-                double bfs[BK][NT];
+        for (int g = 0; g < MP; ++g)
 #pragma unroll
-                for (int b = 0; b < BK; ++b)
-#pragma unroll
-                    for (int tj = 0; tj < NT; ++tj) {
-#ifdef GS_PROBE_NOVALU
-                        bfs[b][tj] = zr1[b][tj];
-#else
-                        bfs[b][tj] = HAS_SRC ? cA[tj] * zr1[b][tj] + cB[tj] * zr2[b][tj] : cA[tj] * zr1[b][tj];
-#endif
-                    }
-                if (u0 + BK < KW) {
-#pragma unroll
-                    for (int b = 0; b < BK; ++b)
-#pragma unroll
-                        for (int tj = 0; tj < NT; ++tj) {
-                            zr1[b][tj] = Zs[bcol[tj] + 4 * (u0 + BK + b)];
-                            if (HAS_SRC) zr2[b][tj] = Zs[so[tj] + 4 * (u0 + BK + b)];
-                        }
+        for (int ub = 0; ub < NB; ++ub) {
+            const int u0 = ub * BK;
+            if (ub == 0) {
+                if (NCH > 1 && g == GROT && prefetch && nx_t < a.d_ub) {   // the collect rotates: chunk 0 was issued GROT generator blocks ago
+                    land_chunk(nx_grp, nx_t, 0, slot ^ 1);
+                    issue_chunk(nx_grp, nx_t, 1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int b = 0; b < BK; ++b)
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                        for (int tj = 0; tj < NT; ++tj)
-                            acc[rt][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfs[b][tj], rt ? af[g][u0 + b].y : af[g][u0 + b].x, acc[rt][tj], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < MP) coef(g + 1, cAn, cBn, son);
             }
+            double bfs[BK][NT];
+#pragma unroll
+            for (int b = 0; b < BK; ++b)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+#if defined(GS_PROBE_NOLDS) || defined(GS_PROBE_NOVALU)   // timing probes (tools/sweep_gs_probe -D...; wrong results)
+                    bfs[b][tj] = zr1[b][tj];
+#else
+                    bfs[b][tj] = HAS_SRC ? cA[tj] * zr1[b][tj] + cB[tj] * zr2[b][tj] : cA[tj] * zr1[b][tj];
 #endif
+                }
+#ifndef GS_PROBE_NOLDS
+            if (ub + 1 < NB) read_raw(u0 + BK, so);
+            else if (g + 1 < MP) read_raw(0, son);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < BK; ++b)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj)
+                        acc[rt][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfs[b][tj], rt ? af[g][u0 + b].y : af[g][u0 + b].x, acc[rt][tj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ub == NB - 1 && g + 1 < MP) {
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) { cA[tj] = cAn[tj]; cB[tj] = cBn[tj]; so[tj] = son[tj]; }
+            }
         }
         GS_MARK(3);
         // ---- step 4: the next item's data lands in the other slot
@@ -648,6 +652,7 @@ hipError_t sweep_gs_prepare() {
     if (e == hipSuccess) e = gs_prepare_one<KU, MP, NT, false>(bytes); \
     if (e == hipSuccess) e = gs_prepare_one<KU, MP, NT, true>(bytes)
     DTO_PREPG(8, 5, 1); DTO_PREPG(8, 5, 2); DTO_PREPG(8, 3, 1); DTO_PREPG(8, 3, 2);
+    DTO_PREPG(4, 5, 1); DTO_PREPG(4, 5, 2); DTO_PREPG(4, 3, 1); DTO_PREPG(4, 3, 2);
 #undef DTO_PREPG
     return e;
 }
@@ -658,7 +663,7 @@ hipError_t sweep_gs_prepare() {
 bool sweep_gs_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_cu, GsSweepPlan& out) {
     const int T = ty.T;
     if (T < 1 || n_int <= 0) return false;
-    if (npad != 256) return false;   // (128 states: KU = 4 -- not instantiated yet)
+    if (npad != 256 && npad != 128) return false;   // clusters of 8 / 4 members of 32 rows each
     if (m + 1 > 5) return false;
     const int KU = npad / 32, R = KU;
     bool has_src = false;
@@ -717,6 +722,7 @@ hipError_t launch_sweep_gs(hipStream_t st, const KProb& P, const KBil& B, const 
     if (pl.KU == KU_ && pl.MP == MP_ && pl.NT == NT_) \
         return pl.has_src ? gs_launch_one<KU_, MP_, NT_, true>(st, a, pl.nblocks, pl.lds_bytes) : gs_launch_one<KU_, MP_, NT_, false>(st, a, pl.nblocks, pl.lds_bytes)
     DTO_GS_CASE(8, 5, 1); DTO_GS_CASE(8, 5, 2); DTO_GS_CASE(8, 3, 1); DTO_GS_CASE(8, 3, 2);
+    DTO_GS_CASE(4, 5, 1); DTO_GS_CASE(4, 5, 2); DTO_GS_CASE(4, 3, 1); DTO_GS_CASE(4, 3, 2);
 #undef DTO_GS_CASE
     return hipErrorInvalidValue;
 }
