@@ -53,6 +53,22 @@ __device__ __forceinline__ double gs_bits_to_d(unsigned long long b) { return __
 __device__ __forceinline__ void gs_st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double gs_ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// max of a non-negative double over the 16 lanes of a DPP row (all lanes of the row get it): rotate right by 8, 4, 2, 1
+template <int CTRL>
+__device__ __forceinline__ double gs_dpp_mov(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double gs_row16_max(double v) {
+    v = fmax(v, gs_dpp_mov<0x128>(v));   // row_ror:8
+    v = fmax(v, gs_dpp_mov<0x124>(v));   // row_ror:4
+    v = fmax(v, gs_dpp_mov<0x122>(v));   // row_ror:2
+    v = fmax(v, gs_dpp_mov<0x121>(v));   // row_ror:1
+    return v;
+}
+
 struct GsArgs {
     KProb P;
     KBil B;
@@ -154,9 +170,11 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
             else af[g][u] = d2{0.0, 0.0};
             // the fragment must STAY in a register: an opaque pass keeps the compiler from re-loading it from memory inside the loop
             // when registers get tight (it did, in a build whose loop it had left partly rolled: 176 global loads per item)
+#ifdef GS_OPAQUE_AF
             double fx = af[g][u].x, fy = af[g][u].y;
             asm volatile("" : "+v"(fx), "+v"(fy));
             af[g][u] = d2{fx, fy};
+#endif
         }
 
     // ---- B operand of this lane: column 16 tj + lr of the group, rows 4 (wave KW + u) + lq of the term columns; padding
@@ -339,12 +357,11 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
     auto signal = [&](int grp) { __hip_atomic_fetch_add(a.arrive + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // successor of local group lg at term t among the active groups: the next one at t, else the first one at t + 1
     auto successor = [&](int lg, int t, int& nlg, int& nt) -> bool {
-        for (int j = lg + 1; j < n_local; ++j)
-            if ((active >> j) & 1ull) { nlg = j; nt = t; return true; }
-        if (t + 1 > a.d_ub) return false;
-        for (int j = 0; j < n_local; ++j)
-            if ((active >> j) & 1ull) { nlg = j; nt = t + 1; return true; }
-        return false;
+        const unsigned long long later = lg >= 63 ? 0ull : active & ~((2ull << lg) - 1ull);
+        if (later) { nlg = __ffsll((long long)later) - 1; nt = t; return true; }
+        if (t + 1 > a.d_ub || active == 0ull) return false;
+        nlg = __ffsll((long long)active) - 1; nt = t + 1;
+        return true;
     };
     auto retire = [&](int lg, int t, bool converged) {
         active &= ~(1ull << lg);
@@ -378,6 +395,16 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
         return go;
     };
 
+    // the (column, row pair) elements this thread finishes in every item: slab offset of the column for interval group 0 (doubles),
+    // the column's interval within its group; -1: a padding column
+    int64_t f_off[FE];
+    int f_int[FE];
+#pragma unroll
+    for (int fe = 0; fe < FE; ++fe) {
+        const int fc = (tid + fe * NTHREADS) >> 4;
+        f_off[fe] = colt[2 * fc] >= 0 ? 2 * (int64_t)colt[2 * fc] + row0 + 2 * (tid & 15) : -1;
+        f_int[fe] = colt[2 * fc + 1];
+    }
     int cur_lg = 0, cur_t = 0, slot = 0;
     bool have = n_local > 0;
     if (have) {
@@ -412,11 +439,10 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
 #pragma unroll
         for (int fe = 0; fe < FE; ++fe) {
             const int e = tid + fe * NTHREADS, fc = e >> 4, frp = e & 15;
-            const int fty = fc < NC ? fc / ipw : 0, fkl = k0 + (fc < NC ? fc - fty * ipw : 0);
             s_prev[fe] = d2{0.0, 0.0};
-            if (fc < NC && fkl < Kpad)
+            if (f_off[fe] >= 0 && k0 + f_int[fe] < Kpad)
                 s_prev[fe] = t == 0 ? *reinterpret_cast<const d2*>(Zs + fc * ZS + row0 + 2 * frp)
-                                    : *reinterpret_cast<const d2*>(a.w.S + ((int64_t)fty * Kpad + fkl) * NPAD + row0 + 2 * frp);
+                                    : *reinterpret_cast<const d2*>(a.w.S + f_off[fe] + (int64_t)k0 * NPAD);
         }
         // ---- step 3: product -- this wavefront's k-slice of every generator
         const int cbase = cur_lg * ipw;
@@ -527,9 +553,8 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
 #pragma unroll
             for (int fe = 0; fe < FE; ++fe) {
                 const int e = tid + fe * NTHREADS, fc = e >> 4, frp = e & 15;
-                const int fty = fc < NC ? fc / ipw : 0, fkl = k0 + (fc < NC ? fc - fty * ipw : 0);
-                const bool fok = fc < NC && fkl < Kpad;
-                const int64_t foff = ((int64_t)fty * Kpad + fkl) * NPAD + row0 + 2 * frp;
+                const bool fok = f_off[fe] >= 0 && k0 + f_int[fe] < Kpad;
+                const int64_t foff = f_off[fe] + (int64_t)k0 * NPAD;
                 d2 sum = *reinterpret_cast<const d2*>(Zs + fc * 32 + 2 * frp);
 #pragma unroll
                 for (int w2 = 1; w2 < NWAVES; ++w2) {
@@ -551,15 +576,15 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
                     bad_t = !(v.x == v.x) || !(v.y == v.y);       // a NaN must survive the max
                     bad_s = !(sv.x == sv.x) || !(sv.y == sv.y);
                 }
-                unsigned long long tb = bad_t ? 0x7ff8000000000000ull : gs_fbits(tmax), sb = bad_s ? 0x7ff8000000000000ull : gs_fbits(smax);
-                unsigned long long t0b = gs_fbits(t0max);
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const unsigned long long t2 = __shfl_xor(tb, o, 64), s2 = __shfl_xor(sb, o, 64), u2 = __shfl_xor(t0b, o, 64);
-                    tb = t2 > tb ? t2 : tb;
-                    sb = s2 > sb ? s2 : sb;
-                    t0b = u2 > t0b ? u2 : t0b;
-                }
+                // maxima over the 16 lanes that share the column (one DPP row): rotations inside the row, vector ALU only; a NaN must
+                // survive the max, so the lanes' NaN flags travel as a ballot and the row's share of it decides
+                tmax = gs_row16_max(tmax); smax = gs_row16_max(smax);
+                if (t == 0) t0max = gs_row16_max(t0max);
+                const unsigned long long nan_t = __ballot(bad_t), nan_s = __ballot(bad_s);
+                const int rsh = lane & 48;
+                const unsigned long long tb = ((nan_t >> rsh) & 0xffffull) ? 0x7ff8000000000000ull : gs_fbits(tmax);
+                const unsigned long long sb = ((nan_s >> rsh) & 0xffffull) ? 0x7ff8000000000000ull : gs_fbits(smax);
+                const unsigned long long t0b = gs_fbits(t0max);
                 if (frp == 0 && fc < NC) {
                     const int p1 = (t + 1) % 3;
                     gs_st_agent(Xg + ((p1 * R + rank) * 2) * NCP + fc, gs_bits_to_d(tb));
@@ -689,7 +714,9 @@ bool sweep_gs_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int n_c
         if (gs_lds_bytes(KU, MPs, NT, cap) > 160 * 1024) continue;
         const double prod_us = 2.0 * NT * (m + 1) * 2 * KU * 64.0 / 2200.0;   // MFMAs per wave x 64 cycles at 2.2 GHz
         const double fix_us = rounds > 1 ? 3.5 : 9.0;   // reduce + publish; a lone group per cluster also exposes its rendezvous and collect
-        const double cost = rounds * (prod_us + fix_us);
+        // (the two-tile instance with source terms at 4 drives is the one the register file cannot quite hold: 35 spilled registers,
+        // measured 7 % slower per column than the one-tile instance)
+        const double cost = rounds * (prod_us + fix_us) * (has_src && NT == 2 && MPs == 5 ? 1.08 : 1.0);
         if (!found || cost < best) {
             found = true; best = cost;
             out.KU = KU; out.MP = m + 1 <= 3 ? 3 : 5; out.NT = NT; out.ipw = ipw; out.has_src = has_src ? 1 : 0;
