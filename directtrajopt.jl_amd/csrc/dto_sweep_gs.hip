@@ -260,8 +260,9 @@ __global__ void __launch_bounds__(256, 1) k_sweep_gs(GsArgs a) {
     auto poll = [&](int grp, int t) {
         long spins = 0;
         while (__hip_atomic_load(a.arrive + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(R * t)) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 19)) { flag[0] = 1; break; }   // a member that never arrives
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 20)) { flag[0] = 1; break; }   // a member that never arrives (~0.3 s: a member may start late when
+                                                                  // another stream's kernels hold CUs at launch)
         }
     };
     // chunk `ch` of the group's term-t columns -> registers (t = 0: the state or the multipliers in the type-0 columns).  Unit e =
