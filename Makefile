@@ -7,7 +7,7 @@ CSRC  := directtrajopt.jl_amd/csrc
 LIB   := directtrajopt.jl_amd/libdto_engine$(if $(TUNING),_t,).so
 O     := $(if $(TUNING),t.o,o)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(if $(TUNING),-DDTO_TUNING,)
-OBJS  := $(addprefix $(CSRC)/,dto_kernels.$(O) dto_small.$(O) dto_sweep_fused.$(O) dto_sweep_gs.$(O) dto_tdb.$(O) dto_hostxfer.$(O) dto_comm.$(O) dto_engine.$(O))
+OBJS  := $(addprefix $(CSRC)/,dto_kernels.$(O) dto_small.$(O) dto_sweep_fused.$(O) dto_sweep_gs.$(O) dto_chain64.$(O) dto_tdb.$(O) dto_hostxfer.$(O) dto_comm.$(O) dto_engine.$(O))
 
 all: $(LIB)
 
@@ -24,6 +24,9 @@ $(CSRC)/dto_sweep_fused.$(O): $(CSRC)/dto_sweep_fused.hip $(CSRC)/dto_kernels.h 
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/dto_sweep_gs.$(O): $(CSRC)/dto_sweep_gs.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/dto_chain64.$(O): $(CSRC)/dto_chain64.hip $(CSRC)/dto_kernels.h $(CSRC)/dto_gemm.hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/dto_hostxfer.$(O): $(CSRC)/dto_hostxfer.cpp $(CSRC)/dto_hostxfer.h

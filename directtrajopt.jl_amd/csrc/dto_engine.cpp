@@ -247,6 +247,7 @@ struct dto_handle {
     int expm_form = 0;  // option "expm_form": 0 = by cost, 2 / 3 = forced
     int overlap_sweep = 1;  // option "overlap_sweep": the Jacobian's generator sweep on a second stream next to the chain's products
     int sweep_form = 0;   // option "sweep_form": 0 = fused persistent sweep where it applies, 1 = step-per-launch form only
+    int chain_form = 0;   // option "chain_form": 0 = the one-launch chain of 33..64-state integrators where it applies, 1 = batched-GEMM launches only
     int n_cu = 256;
     int chain_chunk = 0;  // option "chain_chunk": upper bound on the intervals per chain chunk (0: workspace capacity)
     int deterministic = 0;  // option "deterministic": results independent of overlap_sweep and of the entry-point family
@@ -851,6 +852,39 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     int s_ub = 1;
     if (b1max == b1max && b1max > THETA_16) s_ub = std::isinf(b1max) ? 60 : std::max(1, (int)std::ceil(std::log2(b1max / THETA_16)));
     s_ub = std::min(s_ub, 60);
+    // 33..64 states: the whole chain in ONE launch, a workgroup per interval (dto_chain64.hip) -- no batched-GEMM launches, no
+    // workspace chunks, the evaluation form chosen per interval on the device; the host reads back only what plans the sweep
+    static const int chain64_on = tune_int("DTO_CHAIN64", 1);  // A/B runs (TUNING builds)
+    if (npad == 64 && chain64_on && h->chain_form != 1 && nint <= b.chain_cap) {
+        ChainWork& w = b.chain;
+        HIP_CHECK(hipMemsetAsync(w.smax, 0, 8 * sizeof(int32_t), st));
+        HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
+        int want_form = 0;
+        if (h->expm_form == 2 || h->expm_form == 3) want_form = h->expm_form;
+        {
+            // priced at three powers + three more products per interval (either form, with its squarings, is 5..7 at these norms)
+            ProfScope ps(h, st, CAT_BGEMM, 6.0 * 2.0 * 64.0 * 64.0 * 64.0 * (double)nint);
+            HIP_CHECK(launch_chain64(st, h->P, b.k, dZ, vals, w.norms, w.smax, w.d2max, w.s, s_ub, want_form, h->n_cu));
+        }
+        launch_hump(st, h->P, b.k, dZ, b.d_g1, h->P.kn_lo, (int)nint, w.norms, b.d_hump);
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
+        HIP_CHECK(hipMemcpyAsync(hs, w.smax, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h->h_pinned + 16, b.d_hump, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(h->ev_chain, st));
+        if (in_bubble) in_bubble();
+        HIP_CHECK(hipEventSynchronize(h->ev_chain));
+        h->last_form = 0;   // per interval
+        h->last_smax = hs[0];
+        read_hump(h, b);
+        {
+            double dv;
+            memcpy(&dv, hs + 2, sizeof(double));
+            d2max = dv;
+        }
+        if (h->on_chain_chunk) h->on_chain_chunk(0, (int)nint);
+        if (after_last_enqueue) after_last_enqueue(d2max);
+        return d2max;
+    }
     const double gemm_flops = 2.0 * npad * (double)npad * npad;
     h->last_smax = 0;
     // chunks of equal size (a multiple of 8 intervals) rather than full ones plus a remainder
@@ -1882,6 +1916,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(sweep_fused_prepare());
             HIP_CHECK(sweep_cluster_prepare());
             HIP_CHECK(sweep_gs_prepare());
+            HIP_CHECK(chain64_prepare());
         }
         h->N = d->N; h->K = d->N - 1; h->z = d->z; h->gd = d->gd; h->dt_idx = d->dt_idx;
         h->eval_hessian = d->eval_hessian;
@@ -2940,6 +2975,11 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value) {
     }
     if (std::string(name) == "overlap_sweep") {
         h->overlap_sweep = value != 0;
+        return 0;
+    }
+    if (std::string(name) == "chain_form") {
+        if (value != 0 && value != 1) return fail(h, "dto_set_option: chain_form takes 0 (one launch per call for 33..64 states) or 1 (batched-GEMM launches)");
+        h->chain_form = (int)value;
         return 0;
     }
     if (std::string(name) == "sweep_form") {

@@ -187,6 +187,14 @@ void launch_bgemm_poly(hipStream_t st, int npad, int nb, const ChainWork& w, int
 void launch_bgemm_square(hipStream_t st, int npad, int nb, const ChainWork& w, int src, int dst, int it,
                          const KProb& P, const KBil& B, int64_t int0, double* vals);
 
+// ---- the whole propagator chain of a 33..64-state integrator in ONE launch (dto_chain64.hip): a workgroup per interval keeps
+// A .. A^4, the polynomial factors and the squarings in LDS and registers, chooses the evaluation form per interval and stores
+// -E_k into the slab; norms [n_int][4] (INF, ||A^2||, ||A^3||, ||A^4||: k_hump's input), smax[0] = largest squaring count,
+// d2max = max_k min(d2, max(d3, d4)) (bit pattern), sk [n_int] squarings used
+hipError_t chain64_prepare();
+hipError_t launch_chain64(hipStream_t st, const KProb& P, const KBil& B, const double* dZ, double* vals, double* norms, int32_t* smax,
+                          unsigned long long* d2max, int32_t* sk, int s_cap, int force_form, int n_cu);
+
 struct SweepBuf {      // generator sweep ("expmv") workspace for one bilinear integrator
     int32_t npad, Kpad, TN;   // Kpad multiple of TN
     double* Z[2];      // [T][Kpad][npad] ping-pong terms
@@ -233,6 +241,8 @@ struct FusedSweepPlan {
     int MT, NT, ipw, nslot, nblocks;
     int WC = 1;  // column groups of wavefronts (4 WC wavefronts per workgroup), NT column tiles per group
     int WK = 1;  // 2: two wavefronts per SIMD split the K loop of a wave tile (256 states)
+    int S64 = 0; // 1: the generator-stationary 64-state form (k_sweep_s64), NX = most inhomogeneous sources of a column type
+    int NX = 0;
     size_t lds_bytes;
 };
 hipError_t sweep_fused_prepare();  // per-device opt-in to the kernels' dynamic LDS (dto_create)

@@ -517,6 +517,292 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 64 states (round 4): generators STATIONARY in registers, the K dimension split over the four wavefronts.
+//
+// k_sweep_fused<1, 1> gives a wavefront 16 rows of ONE 16-column tile: one MFMA per k-step, each behind its own generator
+// fragment from L2 and two FP64 vector operations scaling the B fragment (vector and matrix FP64 share a pipe: ~140 cycles
+// per k-step for a 64-cycle MFMA), 80 such steps and two barriers per Taylor term -- 0.24 ms per 1000-knot Jacobian sweep,
+// four times its MFMA time.  Here wavefront w owns k = 16 w .. 16 w + 15 of EVERY generator for ALL 64 rows:
+//   A fragments  (m+1) x 4 k-steps x 4 row tiles = 80 doubles per lane, loaded once per workgroup;
+//   B fragments  rows 16 w .. 16 w + 15 of the 16 term columns -- rows this very wavefront produced the step before (see the
+//                reduction), so the term columns in LDS need no barrier; 4 (+4 per inhomogeneous source) LDS reads and
+//                20 (+20) vector operations per term instead of 160 and 160;
+//   reduction    every wavefront leaves its partial 64 x 16 product in LDS (double-buffered by term parity), ONE barrier, then
+//                wavefront w adds the four partials of row tile w in wavefront order (fixed: results are a function of the data
+//                alone): new term = sum / (t+1) -> sums (registers), column norms (LDS atomics), its rows of the term columns.
+//   termination  the norms of term t+1 are complete only behind the NEXT barrier, so the Al-Mohy--Higham test of the pair
+//                (t, t+1) runs there -- after the partial products of term t+2 were formed, before anything of them is used:
+//                same sums, same term count as the other forms, one wasted product per workgroup.
+// Bound: FP64 MFMA, 80 per wavefront and term (5120 cycles) + ~1000 cycles of everything else.
+struct S64Lds {
+    static constexpr int ZS = 66;   // column pitch: the B-fragment reads of a half-wave fall on 32 distinct 8-byte banks
+    int zs, pb, cg, se, tn, sn, xm, xn, xg, xs, total;  // offsets in doubles
+    __host__ __device__ S64Lds(int T, int m, int ipw) {
+        int o = 0;
+        zs = o; o += 16 * ZS;
+        pb = o; o += 2 * 4 * 4 * 2 * 64 * 2;   // [term parity][row tile][source wavefront][half][lane] 16 bytes
+        cg = o; o += (m + 1) * ipw;
+        se = o; o += ipw;
+        tn = o; o += 4 * 16;
+        sn = o; o += 4 * 16;
+        xm = o; o += 2 * T;
+        xn = o; o += (T + 1) / 2;   // ints, two per double
+        xg = o; o += T;
+        xs = o; o += T;
+        total = o;
+    }
+};
+
+// Column norms travel as the HIGH WORD of |v| (non-negative doubles order like their bit patterns, a NaN's exceeds every
+// finite one): the norm is rounded down by at most 2^-20 of itself, which the termination test does not notice, and the
+// maximum over the 16 lanes of a DPP row takes four 32-bit DPP operations instead of twelve instructions on doubles.
+__device__ __forceinline__ unsigned s64_hi(double v) { return (unsigned)((unsigned long long)__double_as_longlong(fabs(v)) >> 32); }
+template <int CTRL>
+__device__ __forceinline__ unsigned s64_dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned s64_row16_max_u32(unsigned v) {
+    v = max(v, s64_dpp_u32<0x128>(v));   // row_ror:8
+    v = max(v, s64_dpp_u32<0x124>(v));   // row_ror:4
+    v = max(v, s64_dpp_u32<0x122>(v));   // row_ror:2
+    v = max(v, s64_dpp_u32<0x121>(v));   // row_ror:1
+    return v;
+}
+
+template <int MP, int NX>
+__global__ void __launch_bounds__(256, 1) k_sweep_s64(FusedSweepArgs a) {
+    constexpr int ZS = S64Lds::ZS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int Kpad = a.w.Kpad, T = a.ty.T, m = a.B.m, ipw = a.ipw, NC = T * ipw;
+    const int64_t typesz = (int64_t)Kpad * 64;
+    const int k0 = blockIdx.x * ipw;
+    const S64Lds L(T, m, ipw);
+    double* Zs = lds + L.zs;
+    d2* Pb = reinterpret_cast<d2*>(lds + L.pb);
+    double* cg = lds + L.cg;
+    double* sE = lds + L.se;
+    unsigned long long* tn = reinterpret_cast<unsigned long long*>(lds + L.tn);
+    unsigned long long* sn = reinterpret_cast<unsigned long long*>(lds + L.sn);
+    double* xm = lds + L.xm;
+    int* xn = reinterpret_cast<int*>(lds + L.xn);
+    int* xg = reinterpret_cast<int*>(lds + L.xg);
+    int* xs = reinterpret_cast<int*>(lds + L.xs);
+
+    // ---- per-interval coefficients, type table, term 0 (as k_sweep_fused)
+    if (tid < ipw) {
+        const int kl = k0 + tid;
+        const bool live = kl < a.P.n_int;
+        const double* zk = a.Zsrc + (a.P.kn_lo + kl) * a.P.z;
+        const double dt = live ? zk[a.P.dt_idx] : 0.0;
+        const double inv_q = 1.0 / a.q;
+        sE[tid] = dt * inv_q;
+        if (kl < Kpad) {
+            a.w.scaleE[kl] = dt * inv_q;
+            a.w.scaleE[Kpad + kl] = 2.0 * dt * inv_q;
+        }
+        for (int g = 0; g <= m; ++g) {
+            const double ub = live ? (g == 0 ? 1.0 : zk[a.B.u_off + g - 1]) : 0.0;
+            cg[g * ipw + tid] = dt * ub * inv_q;
+            if (kl < Kpad) {
+                a.w.scaleU[(int64_t)g * Kpad + kl] = ub;
+                a.w.scaleA[(int64_t)g * Kpad + kl] = dt * ub * inv_q;
+            }
+        }
+    }
+    if (tid < T) {
+        const TypeDesc td = a.ty.t[tid];
+        xn[tid] = td.n_extra;
+        xg[2 * tid] = td.gen[0]; xg[2 * tid + 1] = td.gen[1];
+        xs[2 * tid] = td.src[0]; xs[2 * tid + 1] = td.src[1];
+        xm[2 * tid] = td.mult[0]; xm[2 * tid + 1] = td.mult[1];
+    }
+    if (tid < 64) { tn[tid] = 0ull; sn[tid] = 0ull; }
+    __syncthreads();
+    {
+        double* Z0 = a.store ? a.w.Zt : a.w.Z[0];
+        for (int c = w; c < 16; c += 4) {
+            const int cc = c < NC ? c : 0;
+            const int ty = cc / ipw, i = cc - ty * ipw, kl = k0 + i;
+            const bool live = c < NC && ty == 0 && kl < a.P.n_int;
+            const int64_t kn = a.P.kn_lo + kl;
+            double v = 0.0;
+            if (live && lane < a.B.n) v = a.src_kind == 0 ? a.Zsrc[kn * a.P.z + a.B.x_off + lane] : a.mu[a.B.row_off + kn * a.B.n + lane];
+            Zs[c * ZS + lane] = v;
+            if (a.store && c < NC && kl < Kpad) Z0[((int64_t)ty * Kpad + kl) * 64 + lane] = v;
+            double mx = fabs(v);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+            if (lane == 0) { tn[c] = fbits(mx); sn[c] = fbits(mx); }
+        }
+    }
+    __syncthreads();
+
+    // ---- B role: lane (lr, lq) feeds column lr, rows 16 w + 4 ks + lq of the term panel
+    const bool bok = lr < NC;
+    const int bty = bok ? lr / ipw : 0, bin = bok ? lr - bty * ipw : 0;
+    double cA[MP];
+#pragma unroll
+    for (int g = 0; g < MP; ++g) cA[g] = bok && g <= m ? cg[g * ipw + bin] : 0.0;
+    const int zoff1 = lr * ZS + 16 * w + lq;
+    int zoff2[NX > 0 ? NX : 1];
+    double cBg[MP][NX > 0 ? NX : 1];
+#pragma unroll
+    for (int x = 0; x < NX; ++x) {
+        const bool has = bok && x < xn[bty];
+        const int gx = has ? xg[2 * bty + x] : -1;
+        const double cb = has ? sE[bin] * xm[2 * bty + x] : 0.0;
+        zoff2[x] = (has ? xs[2 * bty + x] * ipw + bin : lr) * ZS + 16 * w + lq;
+#pragma unroll
+        for (int g = 0; g < MP; ++g) cBg[g][x] = g == gx ? cb : 0.0;
+    }
+    // ---- A role: G_g[row 16 ti + lr][k = 16 w + 4 ks + lq], column-major generators
+    // (generator slots beyond m hold zeros: no branch inside the MFMA stream)
+    double af[MP][4][4];
+#pragma unroll
+    for (int g = 0; g < MP; ++g) {
+        const double* Gg = a.G + (int64_t)(g <= m ? g : 0) * 4096 + (16 * w + lq) * 64 + lr;
+        const double keep = g <= m ? 1.0 : 0.0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) af[g][ks][ti] = keep * Gg[ks * 256 + 16 * ti];
+    }
+    // ---- C role: element r of this lane is row 16 w + lr of column 4 r + lq
+    d4 sreg;
+    unsigned srun[4];
+    bool ok[4];
+    int gcol[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = 4 * r + lq, cc = c < NC ? c : 0;
+        const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
+        ok[r] = c < NC && kl < Kpad;
+        gcol[r] = (ty * Kpad + kl) * 64 + 16 * w + lr;
+        sreg[r] = Zs[c * ZS + 16 * w + lr];
+        srun[r] = s64_hi(sreg[r]);
+    }
+
+    int t_exit = 0;
+    bool conv = false;
+    for (int round = 0; round < a.q; ++round) {
+        if (round > 0) {
+            // next sub-interval of exp(A) = exp(A/q)^q: the sums become term 0 of the new series
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Zs[(4 * r + lq) * ZS + 16 * w + lr] = sreg[r];
+                srun[r] = s64_hi(sreg[r]);
+            }
+            if (tid < 64) { tn[tid] = 0ull; sn[tid] = 0ull; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long mx = (unsigned long long)s64_row16_max_u32(srun[r]) << 32;
+                if (lr == 0 && 4 * r + lq < NC) { atomicMax(&tn[4 * r + lq], mx); atomicMax(&sn[4 * r + lq], mx); }
+            }
+            __syncthreads();
+        }
+        conv = false;
+        int t = 0;
+        for (;; ++t) {
+            if (t < a.d_ub) {
+                // ---- partial products of term t+1 over this wavefront's k range
+                double z1[4], z2[NX > 0 ? NX : 1][4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    z1[ks] = Zs[zoff1 + 4 * ks];
+#pragma unroll
+                    for (int x = 0; x < NX; ++x) z2[x][ks] = Zs[zoff2[x] + 4 * ks];
+                }
+                d4 acc[4];
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) acc[ti] = d4{0.0, 0.0, 0.0, 0.0};
+                // all B fragments first: vector and matrix FP64 share a pipe, an FMA between two MFMAs costs a bubble
+                double bf[MP][4];
+#pragma unroll
+                for (int g = 0; g < MP; ++g)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        bf[g][ks] = cA[g] * z1[ks];
+#pragma unroll
+                        for (int x = 0; x < NX; ++x) bf[g][ks] = fma(cBg[g][x], z2[x][ks], bf[g][ks]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < MP; ++g)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int ti = 0; ti < 4; ++ti)
+                            acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[g][ks], af[g][ks][ti], acc[ti], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                d2* pw = Pb + (size_t)((t & 1) * 16 + w) * 128 + lane;   // [parity][tile][wave][half][lane]
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    pw[ti * 512] = d2{acc[ti][0], acc[ti][1]};
+                    pw[ti * 512 + 64] = d2{acc[ti][2], acc[ti][3]};
+                }
+            }
+            __syncthreads();
+            // ---- Al-Mohy & Higham's test of the pair (t-1, t), whose norms every wavefront has delivered before this barrier
+            if (t >= 1 && t - 1 >= a.tc) {
+                bool more = false;
+                if (lane < NC) {
+                    const double a0 = fbits_to_d(tn[((t - 1) & 3) * 16 + lane]), a1 = fbits_to_d(tn[(t & 3) * 16 + lane]);
+                    const double s = fbits_to_d(sn[(t & 3) * 16 + lane]);
+                    more = !(a0 + a1 <= a.tol * s) && (a0 + a1 == a0 + a1) && s < 1e300;
+                }
+                if (__ballot(more) == 0ull) { conv = true; break; }
+            }
+            if (t == a.d_ub) break;
+            // ---- term t+1 of row tile w: the four partials in wavefront order
+            const double inv = 1.0 / (double)(t + 1);
+            d4 v;
+            {
+                const d2* pr = Pb + (size_t)((t & 1) * 16 + w * 4) * 128 + lane;
+                d2 s0 = pr[0], s1 = pr[64];
+#pragma unroll
+                for (int sw = 1; sw < 4; ++sw) {
+                    const d2 p0 = pr[sw * 128], p1 = pr[sw * 128 + 64];
+                    s0 = d2{s0.x + p0.x, s0.y + p0.y};
+                    s1 = d2{s1.x + p1.x, s1.y + p1.y};
+                }
+                v = d4{s0.x * inv, s0.y * inv, s1.x * inv, s1.y * inv};
+            }
+            double* Zout = a.store ? a.w.Zt + (int64_t)(t + 1) * T * typesz : nullptr;
+            const int slot = ((t + 1) & 3) * 16;
+            unsigned tmax[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sreg[r] += v[r];
+                Zs[(4 * r + lq) * ZS + 16 * w + lr] = v[r];   // this wavefront's rows: the B operand of ITS next k range
+                if (a.store && ok[r]) Zout[gcol[r]] = v[r];
+                tmax[r] = ok[r] ? s64_hi(v[r]) : 0u;
+                srun[r] = max(srun[r], ok[r] ? s64_hi(sreg[r]) : 0u);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned tm = s64_row16_max_u32(tmax[r]), sm = s64_row16_max_u32(srun[r]);
+                if (lr == 0 && ok[r]) {
+                    atomicMax(&tn[slot + 4 * r + lq], (unsigned long long)tm << 32);
+                    atomicMax(&sn[slot + 4 * r + lq], (unsigned long long)sm << 32);
+                }
+            }
+            if (w == 0 && lane < 16) { tn[((t + 2) & 3) * 16 + lane] = 0ull; sn[((t + 2) & 3) * 16 + lane] = 0ull; }
+        }
+        t_exit = conv ? t + 1 : a.d_ub + 1;  // terms 0 .. t_exit - 1 exist
+        if (round + 1 < a.q) __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (ok[r]) a.w.S[gcol[r]] = sreg[r];
+    if (tid == 0) {
+        if (a.w.nterms) a.w.nterms[blockIdx.x] = conv ? t_exit : 0;
+        atomicMax(&a.w.stats[1], t_exit);
+        atomicAdd(&a.w.stats[2], t_exit);
+        if (!conv) atomicAdd(&a.w.stats[0], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // The same sweep with the ROWS of the matrix split over a cluster of R workgroups (round 3).
 //
 // k_sweep_fused gives one workgroup all npad rows of a few intervals; it needs npad <= 256 and at least half a workgroup
@@ -1019,6 +1305,9 @@ hipError_t sweep_fused_prepare() {
     if (e == hipSuccess) e = prepare_one<4, 1, 1, 2>(bytes);
     if (e == hipSuccess) e = prepare_one<4, 2, 1, 2>(bytes);
     if (e == hipSuccess) e = prepare_one<4, 3, 1, 2>(bytes);
+#define DTO_PREP64(MP, NX) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_s64<MP, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+    DTO_PREP64(5, 0); DTO_PREP64(5, 1); DTO_PREP64(5, 2); DTO_PREP64(3, 0); DTO_PREP64(3, 1); DTO_PREP64(3, 2);
+#undef DTO_PREP64
     return e;
 }
 
@@ -1047,6 +1336,22 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
     // 64 and 128 states: the steps are latency-bound (two barriers and an epilogue per handful of MFMAs), several workgroups
     // share a CU, and one column tile per workgroup is fastest -- measured per sweep at 1000 knots, NT = 1 / 2 / 3:
     // 0.24 / 0.30 / 0.44 ms (64 states), 0.61 / 0.73 / 0.86 ms (128 states); three workgroups per CU count as one round.
+    // 64 states, at most 16 columns per interval: the generator-stationary form, as many intervals as a 16-column tile holds
+    // (measured per 1000-knot Jacobian sweep: see DESIGN.md section 4)
+    static const int s64_env = tune_int("DTO_SWEEP_S64", 1);
+    if (npad == 64 && s64_env && m + 1 <= 5 && T <= 16) {
+        int nx = 0;
+        for (int t = 0; t < T; ++t) nx = nx > ty.t[t].n_extra ? nx : ty.t[t].n_extra;
+        const int ipw = 16 / T;
+        const long nblocks = (long)((n_int + ipw - 1) / ipw);
+        if (nx <= 2 && 2 * nblocks >= n_cu) {
+            out.MT = 1; out.NT = 1; out.WC = 1; out.WK = 1; out.ipw = ipw; out.nslot = nslot; out.nblocks = (int)nblocks;
+            out.S64 = 1; out.NX = nx;
+            out.lds_bytes = (size_t)S64Lds(T, m, ipw).total * sizeof(double);
+            return true;
+        }
+    }
+    out.S64 = 0;
     static const double l2_factor[4] = {0.0, 1.6, 1.15, 1.0};
     static const double t_small[2][4] = {{0.0, 0.24, 0.30, 0.44}, {0.0, 0.61, 0.73, 0.86}};
     static const int ipw_env = tune_int("DTO_SWEEP_IPW", 0);  // A/B runs (TUNING builds)
@@ -1207,6 +1512,21 @@ hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, con
     a.G = transposed ? B.GT : B.G;
     a.Zsrc = dZ; a.mu = dmu; a.src_kind = src_kind;
     a.q = q; a.d_ub = d_ub; a.tc = tc; a.ipw = pl.ipw; a.store = store ? 1 : 0; a.nslot = pl.nslot; a.tol = tol;
+    if (pl.S64) {
+        if (w.npad != 64 || B.m + 1 > 5 || ty.T * pl.ipw > 16) return hipErrorInvalidValue;
+#define DTO_GO64(MP, NX) hipLaunchKernelGGL((k_sweep_s64<MP, NX>), dim3(pl.nblocks), dim3(256), pl.lds_bytes, st, a)
+        switch ((B.m + 1 <= 3 ? 0 : 10) + pl.NX) {
+            case 0: DTO_GO64(3, 0); break;
+            case 1: DTO_GO64(3, 1); break;
+            case 2: DTO_GO64(3, 2); break;
+            case 10: DTO_GO64(5, 0); break;
+            case 11: DTO_GO64(5, 1); break;
+            case 12: DTO_GO64(5, 2); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef DTO_GO64
+        return hipGetLastError();
+    }
     if (pl.WC == 2 && pl.MT == 4 && pl.NT == 2) return launch_one<4, 2, 2>(st, a, pl.nblocks, pl.lds_bytes);
     if (pl.WK == 2 && pl.MT == 4 && pl.WC == 1) {
         if (pl.NT == 1) return launch_one<4, 1, 1, 2>(st, a, pl.nblocks, pl.lds_bytes);

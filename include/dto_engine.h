@@ -348,6 +348,9 @@ int dto_bind_output_dev(dto_handle* h, int32_t vector, double* dptr);
  *   different, equally fixed summation order of the generator products).
  *   "sweep_form" (default 0): 0 runs the generator sweep as one persistent launch where that form applies, 1 always one
  *   launch per Taylor step.
+ *   "chain_form" (default 0): 0 runs the propagator chain of a 33..64-state integrator as ONE launch (a workgroup per interval, the
+ *   evaluation form chosen per interval on the device), 1 always as batched-GEMM launches over all intervals (the form of larger
+ *   integrators).  Same approximants and radii either way; results agree to rounding.
  *   "chain_chunk" (default 0 = the engine's workspace budget): at most this many intervals per chunk of the propagator
  *   chain (what a 16000-knot trajectory does by itself; tests use it to exercise the chunk loop on small problems).
  *   "host_xfer_check" (default 0): every host-pointer dto_eval_jacobian / dto_eval_hessian also copies the whole device slab and
