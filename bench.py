@@ -506,7 +506,7 @@ def main():
         chunks = max(1, round(ev.profile_get("build_A")[1] / max(1, args.steps)))
         ms_s, n_s, fl_s = ev.profile_get("expmv")
         var = {}
-        for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("basis", "basis")):
+        for key, nm in (("horner", "bgemm_horner"), ("square", "bgemm_square"), ("plain", "bgemm_plain"), ("chain64", "chain64"), ("basis", "basis")):
             ms_v, n_v, fl_v = ev.profile_get(nm)
             if n_v:
                 var[key] = {"launches": n_v, "avg_launch_ms": ms_v / n_v, "tflops": fl_v / (ms_v * 1e-3) / 1e12}
@@ -548,7 +548,7 @@ def main():
         overlapped = {"avg_launch_ms": ms_gemm / max(n_gemm, 1), "launches": n_gemm,
                       "achieved": fl_gemm / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0,
                       "sweep_ms_per_step": ms_sweep / args.steps,
-                      "note": ("k_bgemm launches of the timed region: the sweep runs next to them on a second stream" if args.callback == "jacobian"
+                      "note": ("the chain's launches of the timed region: the sweep runs next to them on a second stream" if args.callback == "jacobian"
                                else "the adjoint sweep of the timed region: the forward sweep of the p column runs next to it on a second stream")}
         ev.set_option("overlap_sweep", 0)
         ev.profile_enable(True)
@@ -709,7 +709,9 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": {"hessian": "k_sweep_fused / k_sweep_gs (adjoint generator sweep of the Hessian: exp(A')mu and its u-tangents, one persistent launch)",
                                             "constraint": "k_sweep_gs / k_sweep (generator sweep of the p column: exp(A)x)"}.get(
-                                                args.callback, "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
+                                                args.callback, "k_chain64 (the propagator chain of a 33..64-state integrator in ONE launch, a workgroup per interval: "
+                                                               "powers, polynomial products and squarings on FP64 MFMA out of LDS; priced at six 64^3 products per interval)"
+                                                if "chain64" in variants else "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 # HBM-side bytes of ALL kernels of one call from the same PMC passes, against SURVEY.md §8d's algorithmic bytes

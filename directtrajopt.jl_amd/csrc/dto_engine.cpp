@@ -335,7 +335,7 @@ struct ProfScope {
 };
 // (for the bandwidth-bound categories from CAT_ZERO on, `flops` carries the launch's algorithmic BYTES)
 enum { CAT_BGEMM = 0, CAT_SWEEP = 1, CAT_OTHER = 2, CAT_BGEMM_HORNER = 3, CAT_BGEMM_SQUARE = 4, CAT_SWEEP_ADJOINT = 5,
-       CAT_ZERO = 6, CAT_BUILD_A = 7, CAT_ASSEMBLY = 8, CAT_BASIS_MULTI = 9 };
+       CAT_ZERO = 6, CAT_BUILD_A = 7, CAT_ASSEMBLY = 8, CAT_BASIS_MULTI = 9, CAT_CHAIN64 = 10 };
 
 // ------------------------------------------------------------------------------------------
 // structure
@@ -863,7 +863,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
         if (h->expm_form == 2 || h->expm_form == 3) want_form = h->expm_form;
         {
             // priced at three powers + three more products per interval (either form, with its squarings, is 5..7 at these norms)
-            ProfScope ps(h, st, CAT_BGEMM, 6.0 * 2.0 * 64.0 * 64.0 * 64.0 * (double)nint);
+            ProfScope ps(h, st, CAT_CHAIN64, 6.0 * 2.0 * 64.0 * 64.0 * 64.0 * (double)nint);
             HIP_CHECK(launch_chain64(st, h->P, b.k, dZ, vals, w.norms, w.smax, w.d2max, w.s, s_ub, want_form, h->n_cu));
         }
         launch_hump(st, h->P, b.k, dZ, b.d_g1, h->P.kn_lo, (int)nint, w.norms, b.d_hump);
@@ -1001,8 +1001,11 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
 
 bool fused_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store) {
     FusedSweepPlan fp;
-    return h->sweep_form != 1 && !w.frozen && ty.T >= 2 && (!store || (w.Zt && plan.d_ub + 1 <= w.dcap)) &&
-           sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp);
+    if (h->sweep_form == 1 || w.frozen || (store && !(w.Zt && plan.d_ub + 1 <= w.dcap))) return false;
+    if (!sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp)) return false;
+    // single-column sweeps (eval_constraint, the Hessian's forward column): only the 64-state generator-stationary form
+    if (ty.T == 1) return fp.S64 && !(store && h->reuse);   // (a frozen sweep reads nterms_p in blocks of TN intervals)
+    return true;
 }
 
 bool cluster_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty, const SweepPlan& plan, bool store,
@@ -3050,6 +3053,7 @@ int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launch
         else if (!strcmp(name, "bgemm_horner")) cat = CAT_BGEMM_HORNER;
         else if (!strcmp(name, "bgemm_square")) cat = CAT_BGEMM_SQUARE;
         else if (!strcmp(name, "bgemm_plain")) cat = CAT_BGEMM;
+        else if (!strcmp(name, "chain64")) cat = CAT_CHAIN64;
         else if (!strcmp(name, "basis")) any_basis = true;
         else if (!strcmp(name, "basis_k")) cat = CAT_OTHER;
         else if (!strcmp(name, "basis_multi")) cat = CAT_BASIS_MULTI;
@@ -3062,7 +3066,7 @@ int dto_profile_get(dto_handle* h, const char* name, double* ms, int64_t* launch
         double tot = 0, fl = 0;
         int64_t n = 0;
         for (auto& r : h->prof) {
-            if (any_gemm && r.cat != CAT_BGEMM && r.cat != CAT_BGEMM_HORNER && r.cat != CAT_BGEMM_SQUARE) continue;
+            if (any_gemm && r.cat != CAT_BGEMM && r.cat != CAT_BGEMM_HORNER && r.cat != CAT_BGEMM_SQUARE && r.cat != CAT_CHAIN64) continue;
             if (any_basis && r.cat != CAT_OTHER && r.cat != CAT_BASIS_MULTI) continue;
             if (!any_gemm && !any_basis && cat >= 0 && r.cat != cat) continue;
             HIP_CHECK(hipEventSynchronize(r.b));

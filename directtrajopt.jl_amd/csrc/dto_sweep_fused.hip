@@ -1342,9 +1342,12 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
     if (npad == 64 && s64_env && m + 1 <= 5 && T <= 16) {
         int nx = 0;
         for (int t = 0; t < T; ++t) nx = nx > ty.t[t].n_extra ? nx : ty.t[t].n_extra;
-        const int ipw = 16 / T;
+        // a workgroup's Taylor step costs the same for 1 or 16 live columns, so few intervals are spread over the CUs first
+        // (one round of workgroups) and only then packed into the tile
+        int ipw = (int)((n_int + n_cu - 1) / n_cu);
+        ipw = ipw < 1 ? 1 : (ipw > 16 / T ? 16 / T : ipw);
         const long nblocks = (long)((n_int + ipw - 1) / ipw);
-        if (nx <= 2 && 2 * nblocks >= n_cu) {
+        if (nx <= 2) {
             out.MT = 1; out.NT = 1; out.WC = 1; out.WK = 1; out.ipw = ipw; out.nslot = nslot; out.nblocks = (int)nblocks;
             out.S64 = 1; out.NX = nx;
             out.lds_bytes = (size_t)S64Lds(T, m, ipw).total * sizeof(double);

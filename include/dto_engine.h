@@ -375,7 +375,8 @@ int dto_set_option(dto_handle* h, const char* name, int64_t value);
 int dto_profile_enable(dto_handle* h, int32_t on);
 int dto_profile_reset(dto_handle* h);
 /* name: "bgemm" (batched f64 MFMA GEMM of the propagator chain: every template instance), its parts
- * "bgemm_horner" (the products with a fused polynomial epilogue) / "bgemm_square" / "bgemm_plain", "basis"
+ * "bgemm_horner" (the products with a fused polynomial epilogue) / "bgemm_square" / "bgemm_plain" / "chain64" (the one-launch
+ * chain of a 33..64-state integrator, priced at six products per interval), "basis"
  * (generator-subspace GEMM), "expmv" (forward generator sweeps and the pairing products), "expmv_adjoint" (the Hessian's adjoint
  * sweep: its dominant kernel), "all"; "basis_multi" / "basis_k" (the two generator-subspace launches apart: A^2..A^4, and the
  * factor K), and the bandwidth-bound assembly kernels "zero_fill" (the Jacobian's / Hessian's fill!(., 0)), "build_A" (A_k from the

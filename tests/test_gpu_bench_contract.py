@@ -22,7 +22,7 @@ def _line(out):
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n", "64", "--knots", "1200",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n", "128", "--knots", "1200",
                         "--cpu-budget", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
@@ -43,18 +43,30 @@ def test_single_gpu_line():
     assert hr["callback_hbm"]["algorithmic_bytes"] > 0
     si = d["other_callbacks"]["solver_iteration"]   # g, grad f, J, H at a new point per iteration, without / with the shared forward sweep
     assert si["finite"] is True and si["ms_per_iteration"] > 0 and si["ms_per_iteration_reuse_forward_sweep"] > 0, si
-    if "roofline" in hr:   # (64 states x 1200 knots: the adjoint sweep runs in the fused or the cluster form, both timed)
+    if "roofline" in hr:   # (128 states x 1200 knots: the adjoint sweep runs in the fused or the cluster form, both timed)
         assert hr["roofline"]["bound"] == "mfma" and 0 < hr["roofline"]["frac"] < 1
     # round 4: the bandwidth-bound assembly kernels against the HBM roof, the PCIe-inclusive figures and SURVEY 8d's literal metric
     ah = d["assembly_hbm"]
-    for k in ("zero_fill", "build_A"):    # (basis_multi exists from 128 states on: 64 states take the three-GEMM power chain)
+    for k in ("zero_fill", "build_A", "basis_multi"):
         assert ah[k]["unit"] == "GB/s" and ah[k]["achieved"] > 0 and 0 < ah[k]["frac"] < 1.2 and ah[k]["algorithmic_bytes_per_launch"] > 0, (k, ah[k])
     hp = d["host_pointer"]
     assert hp["eval_constraint_jacobian"]["ms_per_call_median"] > 0 and hp["eval_hessian_lagrangian"]["ms_per_call_median"] > 0, hp
     vh = d["value_incl_h2d_median"]
     assert vh["value"] > 0 and vh["ms_per_step_median"] >= 0.9 * d["ms_per_step_median"]
     # the per-instance HBM figures exist for every shape, not only the headline's
-    assert rf["template_instances"]["horner"]["algorithmic_hbm_bytes"] == 7 * 8.0 * 64 * 64 * 1199
+    assert rf["template_instances"]["horner"]["algorithmic_hbm_bytes"] == 7 * 8.0 * 128 * 128 * 1199
+
+
+def test_64_states_report_the_one_launch_chain():
+    """configs[1]'s shape: the propagator chain is k_chain64 (one launch per call), the sweep the generator-stationary form; the line says so."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--n", "64", "--knots", "1000",
+                        "--no-cpu-baseline", "--no-other-callbacks"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    rf = d["roofline"]
+    assert "k_chain64" in rf["kernel"] and rf["launches"] == 3 and 0 < rf["frac"] < 1, rf
+    assert set(rf["template_instances"]) >= {"chain64"} and "horner" not in rf["template_instances"]
+    assert d["config"]["outputs_finite"] is True and d["assembly_hbm"]["zero_fill"]["achieved"] > 0
 
 
 @pytest.mark.parametrize("callback", ["hessian", "constraint"])
