@@ -31,6 +31,7 @@ namespace dto {
 
 namespace {
 
+typedef unsigned int c64_u4 __attribute__((ext_vector_type(4)));
 constexpr int C64_P = 66;              // LDS pitch of a 64 x 64 matrix (doubles)
 constexpr int C64_MAT = 64 * C64_P;    // doubles per matrix
 
@@ -44,7 +45,15 @@ struct Chain64Args {
     unsigned long long* d2max;   // max_k min(d2, max(d3, d4)) as a bit pattern
     int32_t* sk;           // [n_int] squarings used (diagnostics, host hand-off planning)
     int s_cap, force_form;
+#ifdef C64_STAMP
+    unsigned long long* stamp;   // diagnostic builds (tools/chain64_probe -DC64_STAMP): s_memtime at the phase boundaries of block 0's first interval
+#endif
 };
+#ifdef C64_STAMP
+#define C64_MARK(i) do { if (blockIdx.x == 0 && tid == 0 && kl == blockIdx.x) a.stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C64_MARK(i) do { } while (0)
+#endif
 
 // sum over the 16 lanes of a DPP row (all lanes of the row get it), fixed order
 template <int CTRL>
@@ -68,12 +77,26 @@ __device__ __forceinline__ void c64_product(const double* __restrict__ X, const 
     for (int ti = 0; ti < 4; ++ti) acc[ti] = d4{0.0, 0.0, 0.0, 0.0};
     const double* yp = Y + (16 * wave + lr) * C64_P + lq;     // right operand: column 16 w + lr, row 4 ks + lq
     const double* xp = X + lq * C64_P + lr;                    // left operand: column 4 ks + lq, row 16 ti + lr
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-        const double yf = yp[4 * ks];
+    // the fragments of k-step ks + 1 are read before the MFMAs of k-step ks are issued: one wavefront per SIMD has nobody else
+    // to hide its LDS latency behind
+    double yf = yp[0], xf[4];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-            acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(yf, xp[4 * ks * C64_P + 16 * ti], acc[ti], 0, 0, 0);
+    for (int ti = 0; ti < 4; ++ti) xf[ti] = xp[16 * ti];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        double yn = 0.0, xn[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ks + 1 < 16) {
+            yn = yp[4 * (ks + 1)];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) xn[ti] = xp[4 * (ks + 1) * C64_P + 16 * ti];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(yf, xf[ti], acc[ti], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        yf = yn;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) xf[ti] = xn[ti];
     }
 }
 __device__ __forceinline__ void c64_store(double* __restrict__ M, int wave, int lr, int lq, const d4 (&acc)[4]) {
@@ -112,23 +135,55 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
         const int64_t kn = a.P.kn_lo + kl;
         const double* zk = a.Z + kn * a.P.z;
         __syncthreads();   // the previous interval's LDS is done with
+        C64_MARK(0);
         // ---- A = dt (G_0 + sum_j u_j G_j): one pass over the generators (padded 64 x 64, column-major)
         {
             const double dt = zk[a.P.dt_idx];
             double ub[MAX_DRIVES + 1];
             ub[0] = dt;
             for (int j = 0; j < m; ++j) ub[j + 1] = dt * zk[a.B.u_off + j];
-            for (int i = tid; i < 64 * 32; i += 256) {       // 16-byte units
-                const int c = i >> 5, r2 = (i & 31) * 2;
-                d2 s = d2{0.0, 0.0};
-                for (int j = 0; j <= m; ++j) {
-                    const d2 g = *reinterpret_cast<const d2*>(a.B.G + (int64_t)j * 4096 + c * 64 + r2);
-                    s.x += ub[j] * g.x; s.y += ub[j] * g.y;
+            if (m <= 4) {
+                // five generators at most: 20 loads of this lane in flight at once (coefficient 0 and generator 0 beyond m)
+                // (buffer loads: one 32-bit lane offset, the generator and the column group in the scalar offset -- no address
+                // registers to keep per load)
+                const int voff = ((tid >> 5) * 64 + (tid & 31) * 2) * 8;   // 16-byte unit tid: column tid / 32, rows 2 (tid % 32)
+                double* const dst0 = M0 + (tid >> 5) * C64_P + (tid & 31) * 2;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.B.G), 0, (m + 1) * 32768, 0x00020000);
+                union U { c64_u4 u; d2 d; };
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    U g[5][4];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int sj = (j <= m ? j : 0) * 32768;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) g[j][u].u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sj + 4096 * (4 * half + u), 0);   // 8 columns on
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        d2 s = d2{0.0, 0.0};
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const double cj = j <= m ? ub[j] : 0.0;
+                            s.x += cj * g[j][u].d.x; s.y += cj * g[j][u].d.y;
+                        }
+                        *reinterpret_cast<d2*>(dst0 + 8 * (4 * half + u) * C64_P) = s;
+                    }
                 }
-                *reinterpret_cast<d2*>(M0 + c * C64_P + r2) = s;
+            } else {
+                for (int i = tid; i < 64 * 32; i += 256) {       // 16-byte units
+                    const int c = i >> 5, r2 = (i & 31) * 2;
+                    d2 s = d2{0.0, 0.0};
+                    for (int j = 0; j <= m; ++j) {
+                        const d2 g = *reinterpret_cast<const d2*>(a.B.G + (int64_t)j * 4096 + c * 64 + r2);
+                        s.x += ub[j] * g.x; s.y += ub[j] * g.y;
+                    }
+                    *reinterpret_cast<d2*>(M0 + c * C64_P + r2) = s;
+                }
             }
         }
         __syncthreads();
+        C64_MARK(1);
         // ---- powers and their 1-norms
         d4 acc[4];
         double nrm[3];
@@ -136,6 +191,7 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
         nrm[0] = c64_strip_norm1(acc);
         c64_store(M1, wave, lr, lq, acc);
         __syncthreads();
+        C64_MARK(2);
         c64_product(M1, M0, wave, lr, lq, acc);
         nrm[1] = c64_strip_norm1(acc);
         c64_store(M2, wave, lr, lq, acc);
@@ -144,6 +200,7 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
         c64_store(M3, wave, lr, lq, acc);
         if (lane == 0) { red[0 * 4 + wave] = nrm[0]; red[1 * 4 + wave] = nrm[1]; red[2 * 4 + wave] = nrm[2]; }
         __syncthreads();
+        C64_MARK(3);
         double N[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -190,6 +247,7 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
             }
             cL[5] = EXPM3_AL; cR[5] = EXPM3_BE;
         }
+        C64_MARK(4);
         // ---- the polynomials at this lane's 16 elements, from the four powers: element e = (ti, r) is row 16 ti + lr,
         // column 16 w + 4 r + lq
         d4 pK[4], pA[4], pB[4], pC[4], pL[4], pR[4];
@@ -209,8 +267,10 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
                 pR[ti][r] = cR[0] * id + cR[1] * a1 + cR[2] * a2 + cR[3] * a3 + cR[4] * a4;
             }
         __syncthreads();   // every lane has read the powers: A, A^2, A^3 may go (A^4 stays: left operand of Y)
+        C64_MARK(5);
         c64_store(M0, wave, lr, lq, pK);
         __syncthreads();
+        C64_MARK(6);
         // ---- Y = A^4 K -> Ya = Y + Pa (M1), Yb = Y + Pb (M2)
         c64_product(M3, M0, wave, lr, lq, acc);
         d4 ya[4];
@@ -221,6 +281,7 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
         c64_store(M1, wave, lr, lq, ya);
         c64_store(M2, wave, lr, lq, pB);
         __syncthreads();
+        C64_MARK(7);
         c64_product(M1, M2, wave, lr, lq, acc);   // Ya Yb
         double* cur = M0;      // where the current result lives
         double* oth = M3;
@@ -249,6 +310,7 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ti][r] += pC[ti][r];
         }
+        C64_MARK(8);
         // ---- squarings
         for (int it = 0; it < s; ++it) {
             __syncthreads();   // the operands of the product that made `acc` are free
@@ -257,6 +319,7 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
             c64_product(cur, cur, wave, lr, lq, acc);
             double* t = cur; cur = oth; oth = t;
         }
+        C64_MARK(9);
         // ---- -E_k into the x_k columns of the slab: column x_off + col of knot k, rows of interval k (part 1)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -270,10 +333,15 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
                 }
             }
         }
+        C64_MARK(10);
     }
 }
 
 }  // namespace
+
+#ifdef C64_STAMP
+unsigned long long* c64_stamp_buffer = nullptr;   // set by the probe
+#endif
 
 hipError_t chain64_prepare() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain64), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -285,6 +353,9 @@ hipError_t launch_chain64(hipStream_t st, const KProb& P, const KBil& B, const d
     Chain64Args a{};
     a.P = P; a.B = B; a.Z = dZ; a.vals = vals; a.norms = norms; a.smax = smax; a.d2max = d2max; a.sk = sk;
     a.s_cap = s_cap; a.force_form = force_form;
+#ifdef C64_STAMP
+    a.stamp = c64_stamp_buffer;
+#endif
     const size_t lds = ((size_t)4 * C64_MAT + 16) * sizeof(double);
     const int64_t grid = P.n_int < (int64_t)n_cu ? P.n_int : (int64_t)n_cu;   // one 135 KB workgroup per CU, grid-stride over the intervals
     hipLaunchKernelGGL(k_chain64, dim3((unsigned)grid), dim3(256), lds, st, a);

@@ -231,7 +231,8 @@ struct dto_handle {
     int64_t* d_crow_col = nullptr;
     int64_t* d_crow_pos = nullptr;
     int64_t* d_con_rows = nullptr;       // constraint-pattern rows, (col,row) order
-    double* h_pinned = nullptr;  // [32]: 0-1 bounds, 2-3 chain scalars, 6 sweep stats, 16-23 hump readback
+    double* h_pinned = nullptr;  // [32]: 0-1 bounds, 2-3 chain scalars, 6 sweep stats, 16-23 hump readback, 28 deferred squaring count
+    bool smax_pending = false;   // the one-launch chain's squaring count lands in h_pinned[28] behind ev_done (read by check_sweeps)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
     hipStream_t stream_rb = nullptr; // the chain's 96-byte readback (evaluation form, squaring counts, hump bound) leaves on this one
@@ -594,6 +595,12 @@ bool gs_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, 
                       bool shared_chip, GsSweepPlan& gp);
 bool ensure_bind_runs(dto_handle* h, int which);
 
+// 33..64 states: the propagator chain as one launch (dto_chain64.hip)
+bool chain64_applies(const dto_handle* h, const BilHost& b) {
+    static const int chain64_on = tune_int("DTO_CHAIN64", 1);  // A/B runs (TUNING builds)
+    return b.k.npad == 64 && chain64_on && h->chain_form != 1 && h->P.n_int <= b.chain_cap;
+}
+
 // Returns the number of Taylor steps enqueued in the last round.  store = true keeps every term in w.Zt
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
@@ -842,7 +849,8 @@ int chunk_size(const dto_handle* h, int npad) {
 // is then busy with the Taylor products and squarings): the caller uses it to drive the generator sweep on a
 // second stream so that both proceed concurrently.
 double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, double b1max, hipStream_t st,
-                 const std::function<void(double)>& after_last_enqueue = nullptr, const std::function<void()>& in_bubble = nullptr) {
+                 const std::function<void(double)>& after_last_enqueue = nullptr, const std::function<void()>& in_bubble = nullptr,
+                 bool nothing_waits = false) {
     const int npad = b.k.npad;
     const int64_t nint = h->P.n_int;
     double d2max = 0.0;
@@ -854,8 +862,7 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
     s_ub = std::min(s_ub, 60);
     // 33..64 states: the whole chain in ONE launch, a workgroup per interval (dto_chain64.hip) -- no batched-GEMM launches, no
     // workspace chunks, the evaluation form chosen per interval on the device; the host reads back only what plans the sweep
-    static const int chain64_on = tune_int("DTO_CHAIN64", 1);  // A/B runs (TUNING builds)
-    if (npad == 64 && chain64_on && h->chain_form != 1 && nint <= b.chain_cap) {
+    if (chain64_applies(h, b)) {
         ChainWork& w = b.chain;
         HIP_CHECK(hipMemsetAsync(w.smax, 0, 8 * sizeof(int32_t), st));
         HIP_CHECK(hipMemsetAsync(b.d_hump, 0, 8 * sizeof(unsigned long long), st));
@@ -865,6 +872,17 @@ double run_chain(dto_handle* h, BilHost& b, const double* dZ, double* vals, doub
             // priced at three powers + three more products per interval (either form, with its squarings, is 5..7 at these norms)
             ProfScope ps(h, st, CAT_CHAIN64, 6.0 * 2.0 * 64.0 * 64.0 * 64.0 * (double)nint);
             HIP_CHECK(launch_chain64(st, h->P, b.k, dZ, vals, w.norms, w.smax, w.d2max, w.s, s_ub, want_form, h->n_cu));
+        }
+        if (nothing_waits) {
+            // the caller has planned and enqueued its sweep already: nothing on the host depends on this launch, the call stays
+            // enqueue-only; the squaring count (a diagnostic) is read with the sweep statistics at the next entry point
+            HIP_CHECK(hipMemcpyAsync(h->h_pinned + 28, w.smax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            h->smax_pending = true;
+            h->last_form = 0;
+            if (in_bubble) in_bubble();
+            if (h->on_chain_chunk) h->on_chain_chunk(0, (int)nint);
+            if (after_last_enqueue) after_last_enqueue(0.0);
+            return 0.0;
         }
         launch_hump(st, h->P, b.k, dZ, b.d_g1, h->P.kn_lo, (int)nint, w.norms, b.d_hump);
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_pinned + 2);
@@ -1114,9 +1132,9 @@ SweepPlan plan_hump(const BilHost& b, double beta_fallback) {
 // (max_k beta^k / k! <= e^9, the same four digits plan_hump allows): at the benchmark shape the triangle-inequality bound on
 // ||A^2||^(1/2) is 9.5, just past the beta <= 9 rule, and the exact norm (a store-less basis GEMM, a kernel for the hump and two
 // host round trips: 0.2 of the callback's 1.1 ms) was bought only to learn what this already shows.
-SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, bool loose = false) {
-    Bounds bd = get_bounds(h, b, dZ, st);
-    if (plan_sweep(bd.beta).q == 1) return plan_sweep(bd.beta);  // the cheap bound already gives one round
+// The step budget the cheap generator-norm bound alone gives, where that is a single round (q = 1): no exact norm needed.
+bool cheap_plan(const Bounds& bd, bool loose, SweepPlan& out) {
+    if (plan_sweep(bd.beta).q == 1) { out = plan_sweep(bd.beta); return true; }  // the cheap bound already gives one round
     if (loose && bd.beta == bd.beta && bd.beta < 40.0) {
         double lh = 0.0;
         for (int k = 1; k < 200; ++k) lh = std::max(lh, k * std::log(bd.beta) - std::lgamma(k + 1.0));
@@ -1131,9 +1149,17 @@ SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st,
             // sum, Al-Mohy & Higham's own criterion, which they apply from the first term on) starts a few terms past the peak
             // of the BOUND -- a function of Z alone, like d_ub / 2 - 1, but not inflated by the bound's slack in the tail
             p.tc = std::min(p.d_ub / 2 - 1, std::max(2, (int)std::ceil(bd.beta) + 4));
-            return p;
+            out = p;
+            return true;
         }
     }
+    return false;
+}
+
+SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st, bool loose = false) {
+    Bounds bd = get_bounds(h, b, dZ, st);
+    SweepPlan cheap;
+    if (cheap_plan(bd, loose, cheap)) return cheap;
     double d2 = exact_d2(h, b, dZ, st);
     auto plan = [&] { return plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2); };
     if (d2 == d2 && plan().q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);  // ||A^3||, ||A^4|| sharpen the bound
@@ -1300,12 +1326,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
                 HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
             }
-            run_chain(h, b, dZ, dvals, INFINITY, st, [&](double d2) {
-                bd = Bounds{h->h_pinned[0], h->h_pinned[1]};  // copied before the chain's readback event
-                // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
-                // (and still rigorous) growth rate for the sweep's step budget
-                if (same && b.cache_kind >= 2) return;  // the tangent sums of this very point are still in b.fw
-                SweepPlan plan = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);
+            auto sweep_with = [&](SweepPlan plan) {
                 SweepTypes ty = make_types(b.k.m, false);
                 // the p column of this very point is stored (eval_constraint or a Hessian came first)
                 const bool have_p = same && b.p_terms && plan.q == 1;
@@ -1343,13 +1364,43 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
                 if (keep || plan.q > 1) b.p_terms = false;  // the store now holds every column type / the scale factors changed
+            };
+            // One-launch chain (33..64 states): the chain's exact norms arrive only when ALL of it is done, so a sweep planned from
+            // them would run behind it.  Where the cheap bound already gives a single round, the sweep is planned from that bound
+            // (as eval_constraint and the Hessian do) and enqueued FIRST, on the second stream: its workgroups and the chain's
+            // share the CUs (64 x 1000: 0.42 -> 0.3x ms per Jacobian).
+            bool swept = same && b.cache_kind >= 2;  // the tangent sums of this very point are still in b.fw
+            bool zeroed = false;
+            static const int early_on = tune_int("DTO_SWEEP_EARLY", 1);  // A/B runs (TUNING builds)
+            if (!swept && early_on && chain64_applies(h, b)) {   // (with or without overlap: the plan, hence the bits, must not depend on it)
+                HIP_CHECK(hipStreamSynchronize(st));
+                bd = Bounds{h->h_pinned[0], h->h_pinned[1]};
+                SweepPlan early;
+                if (cheap_plan(bd, /*loose=*/true, early)) {
+                    if (lone && !keep_constants) {
+                        // (the fill no longer has a host wait to hide in: it goes first, beside the sweep)
+                        ProfScope ps(h, st, CAT_ZERO, 8.0 * ((double)h->info.jac_len - (double)h->P.n_int * b.k.n * b.k.n));
+                        launch_jac_zero(st, h->P, b.k, dvals);
+                        zeroed = true;
+                    }
+                    sweep_with(early);
+                    swept = true;
+                }
+            }
+            const bool nothing_waits = swept && chain64_applies(h, b);
+            run_chain(h, b, dZ, dvals, INFINITY, st, [&](double d2) {
+                bd = Bounds{h->h_pinned[0], h->h_pinned[1]};  // copied before the chain's readback event
+                // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
+                // (and still rigorous) growth rate for the sweep's step budget
+                if (swept) return;
+                sweep_with(plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2));
             }, [&] {
-                if (lone && !keep_constants) {
+                if (lone && !keep_constants && !zeroed) {
                     // every entry but the -E_k blocks, which the chain overwrites
                     ProfScope ps(h, st, CAT_ZERO, 8.0 * ((double)h->info.jac_len - (double)h->P.n_int * b.k.n * b.k.n));
                     launch_jac_zero(st, h->P, b.k, dvals);
                 }
-            });
+            }, nothing_waits);
             if (overlap) {
                 HIP_CHECK(hipEventRecord(h->ev_join, ss));
                 HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1737,6 +1788,7 @@ void check_sweeps(dto_handle* h, bool wait = true) {
     if (!wait && hipEventQuery(h->ev_done) != hipSuccess) { (void)hipGetLastError(); return; }
     h->stats_pending = false;
     HIP_CHECK(hipEventSynchronize(h->ev_done));
+    if (h->smax_pending) { h->last_smax = *reinterpret_cast<const int32_t*>(h->h_pinned + 28); h->smax_pending = false; }
     size_t i = 0;
     bool bad = false;
     for (auto& b : h->bil)
@@ -1774,6 +1826,7 @@ int guarded(dto_handle* h, F&& f, int mode = G_PLAIN, hipStream_t st = nullptr) 
     } catch (const HipError& e) {
         drop_caches(h);
         h->stats_pending = false;
+        h->smax_pending = false;
         return fail(h, e.msg);
     } catch (const std::exception& e) {
         drop_caches(h);
