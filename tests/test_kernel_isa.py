@@ -46,3 +46,40 @@ def test_generator_fragments_stay_in_registers(isa):
             m = re.search(r"v_mfma_f64_16x16x4_f64 \S+ \S+ (\S+),", body[k])
             ops.add(m.group(1))
         assert len(ops) >= 2 * (2 * ku) * min(mp, 5) * 0.9, (nm, len(ops))   # distinct register pairs (zero generators of padded slots may share)
+
+
+# ---- the 64-state generator-stationary K-split sweep (k_sweep_s64 in csrc/dto_sweep_fused.hip)
+SRC_FUSED = os.path.join(ROOT, "directtrajopt.jl_amd", "csrc", "dto_sweep_fused.hip")
+
+
+@pytest.fixture(scope="module")
+def isa_fused(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "fused.s"
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-I", os.path.dirname(SRC_FUSED), SRC_FUSED, "-o", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+def test_s64_generators_stay_in_registers_and_the_mfma_stream_is_clean(isa_fused):
+    """80 (48) stationary generator doubles per lane loaded ONCE, before the Taylor loop; per term one uninterrupted stream of
+    16 MP MFMAs with no memory instruction, no scratch and no accumulator shuffling between register files inside it (a build
+    with a branch per generator moved all 32 accumulator registers VGPR <-> AGPR around every block of 16)."""
+    names = re.findall(r"^(_ZN3dto12_GLOBAL__N_111k_sweep_s64ILi(\d)ELi(\d)EEEvNS0_14FusedSweepArgsE):", isa_fused, re.M)
+    assert len(names) == 6, names                              # MP in {5, 3} x NX in {0, 1, 2}
+    for nm, mp, nx in names:
+        mp = int(mp)
+        body = isa_fused[isa_fused.index(nm + ":"):]
+        body = body[:body.index("s_endpgm")].split("\n")
+        assert not any("scratch_" in l for l in body), nm
+        mf = [k for k, l in enumerate(body) if "v_mfma_f64_16x16x4_f64" in l]
+        assert len(mf) % (16 * mp) == 0 and 1 <= len(mf) // (16 * mp) <= 2, (nm, len(mf))   # (the first term may be peeled)
+        first = mf[0]
+        # the stationary loads all come before the first MFMA ...
+        assert sum(1 for l in body[:first] if re.search(r"\bglobal_load_dwordx2", l)) >= 16 * mp, nm
+        for s in range(0, len(mf), 16 * mp):
+            inside = body[mf[s]:mf[s + 16 * mp - 1] + 1]
+            # ... and each stream of 16 MP MFMAs holds nothing that touches memory, and no accumulator shuffling (the largest
+            # instance parks six stationary fragments in AGPRs and reads them back: 12 moves, tolerated)
+            assert not any(re.search(r"\b(global_|buffer_|ds_|v_accvgpr_write)", l) for l in inside), nm
+            assert sum(1 for l in inside if "v_accvgpr_read" in l) <= 16, nm
