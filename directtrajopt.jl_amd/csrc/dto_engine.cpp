@@ -236,7 +236,7 @@ struct dto_handle {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // generator sweep runs here, concurrently with the propagator chain
     hipStream_t stream_rb = nullptr; // the chain's 96-byte readback (evaluation form, squaring counts, hump bound) leaves on this one
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr, ev_chain = nullptr, ev_rb = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stats = nullptr, ev_chain = nullptr, ev_rb = nullptr, ev_zero = nullptr;
 
     bool reuse = false;          // option reuse_forward_sweep
     double* d_Zcache = nullptr;  // the Z the cached sweeps belong to
@@ -289,6 +289,7 @@ dto_handle::~dto_handle() {
     if (stream_rb) (void)hipStreamDestroy(stream_rb);
     if (ev_rb) (void)hipEventDestroy(ev_rb);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_zero) (void)hipEventDestroy(ev_zero);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_stats) (void)hipEventDestroy(ev_stats);
     if (ev_chain) (void)hipEventDestroy(ev_chain);
@@ -1423,13 +1424,33 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
 }
 
 void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu, double* dH, hipStream_t st) {
+    static const int zero_beside_on = tune_int("DTO_HESS_ZERO_BESIDE", 1);  // A/B runs (TUNING builds)
+    // (worth an event round only for a large slab: 5.57 -> 5.49 ms at 256 x 2000, +4 us at 64 x 1000 and 256 x 250)
+    const bool zero_beside = zero_beside_on && h->overlap_sweep != 0 && h->P.n_int > 0 && !h->bil.empty() && !h->bil[0].small &&
+                             (size_t)h->info.hess_len * sizeof(double) >= ((size_t)256 << 20) &&
+                             !h->integ_kind.empty() && h->integ_kind[0] == DTO_INTEGRATOR_BILINEAR;
+    bool zero_joined = true;
     if (h->bound[1] == dH && h->primed[1] && ensure_bind_runs(h, 1))   // bound output: structural zeros are in place
         launch_zero_runs(st, h->d_bind_start[1], h->d_bind_len[1], h->n_bind_runs[1], dH);
-    else
-    {
+    else if (zero_beside) {
+        // fill!(H, 0), evaluator.jl:571 -- on the second stream: the fill is HBM-bound, the sweeps that open the bilinear block
+        // are MFMA-bound and write nothing into H, so the 1.7 GB (256 x 2000) are cleared underneath them; the first kernel
+        // that writes H waits for it (need_zero)
+        HIP_CHECK(hipEventRecord(h->ev_fork, st));  // whatever used H before on this stream is done
+        HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        {
+            ProfScope ps(h, h->stream2, CAT_ZERO, 8.0 * (double)h->info.hess_len);
+            HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, h->stream2));
+        }
+        HIP_CHECK(hipEventRecord(h->ev_zero, h->stream2));
+        zero_joined = false;
+    } else {
         ProfScope ps(h, st, CAT_ZERO, 8.0 * (double)h->info.hess_len);
         HIP_CHECK(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)h->info.hess_len, st));  // fill!(H, 0), evaluator.jl:571
     }
+    auto need_zero = [&] {
+        if (!zero_joined) { HIP_CHECK(hipStreamWaitEvent(st, h->ev_zero, 0)); zero_joined = true; }
+    };
     const bool same = same_point(h, dZ, st);
     // integrators in reference order (evaluator.jl:574-598)
     for (size_t i = 0; i < h->integ_kind.size(); ++i) {
@@ -1437,6 +1458,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             BilHost& b = h->bil[h->integ_index[i]];
             if (h->P.n_int <= 0) continue;
             if (b.small) {
+                need_zero();
                 HIP_CHECK(launch_small(st, h->P, b.k, b.d_Gs, make_types(b.k.m, true), make_types(b.k.m, false), dZ, dmu, nullptr, nullptr, dH, 4));
                 continue;
             }
@@ -1506,6 +1528,7 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                         break;
                     }
             launch_apply_Gu(st, b.k, b.ad, 1, b.ad.S, b.ad.GY);
+            need_zero();
             launch_hess_bilinear(st, h->P, b.k, b.fw, b.ad, dmu, dH, pair ? 0 : 1);
             if (pair) {
                 // (u_i,u_j) block from the stored Taylor terms (no second-order columns): Beta-weighted sums U_a of the
@@ -1523,16 +1546,20 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
                 launch_hess_pair(st, h->P, b.k, b.ad, na, b.EP, dH);
             }
         } else if (h->integ_kind[i] == DTO_INTEGRATOR_DERIVATIVE) {
+            need_zero();
             launch_hess_derivative(st, h->P, h->der[h->integ_index[i]], dmu, dH);
         } else if (h->integ_kind[i] == DTO_INTEGRATOR_TIME_DEPENDENT_BILINEAR) {
+            need_zero();
             TdbHost& t = h->tdb[h->integ_index[i]];
             tdb_eval(h, t, dZ, dmu, 2, st);
             launch_extint_hess(st, h->P, t.place, t.d_hess, dH);
         } else {  // the caller's blocks already carry mu_k (eval_hessian_of_lagrangian(integrator, traj, mu_slice))
+            need_zero();
             const int e = h->integ_index[i];
             launch_extint_hess(st, h->P, h->ext_int[e], ext_upload(h, e, 2, st), dH);
         }
     }
+    need_zero();
     for (auto& c : h->con) {
         if (!c.external) launch_hess_knot(st, h->P, c.k, dZ, dmu, dH);
         else if (c.k.n_times > 0)  // the caller's blocks already carry mu_i (knot_point_constraint.jl:283-291)
@@ -1964,6 +1991,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
             HIP_CHECK(hipStreamCreateWithFlags(&h->stream_rb, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_rb, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_zero, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
