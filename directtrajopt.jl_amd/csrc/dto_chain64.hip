@@ -129,9 +129,15 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
     double* M2 = lds + 2 * C64_MAT;    // A^3, later Y + Pb, later R / squaring pong
     double* M3 = lds + 3 * C64_MAT;    // A^4
     double* red = lds + 4 * C64_MAT;   // [3][4] norm shares of the wavefronts
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int tid0 = threadIdx.x;
     const int n = a.B.n, m = a.B.m;
     for (int64_t kl = blockIdx.x; kl < a.P.n_int; kl += gridDim.x) {
+        // the lane coordinates are made opaque once per interval: otherwise the compiler computes the ~100 LDS offsets of the
+        // unrolled product loops ONCE, outside this loop, and keeps them alive across it -- in scratch (46 spilled registers, reloaded
+        // in the middle of the MFMA streams); recomputing an offset is one integer instruction
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
         const int64_t kn = a.P.kn_lo + kl;
         const double* zk = a.Z + kn * a.P.z;
         __syncthreads();   // the previous interval's LDS is done with
@@ -143,32 +149,29 @@ __global__ void __launch_bounds__(256, 1) k_chain64(Chain64Args a) {
             ub[0] = dt;
             for (int j = 0; j < m; ++j) ub[j + 1] = dt * zk[a.B.u_off + j];
             if (m <= 4) {
-                // five generators at most: 20 loads of this lane in flight at once (coefficient 0 and generator 0 beyond m)
+                // five generators at most: all 40 loads of this lane in flight at once (coefficient 0 and generator 0 beyond m)
                 // (buffer loads: one 32-bit lane offset, the generator and the column group in the scalar offset -- no address
                 // registers to keep per load)
                 const int voff = ((tid >> 5) * 64 + (tid & 31) * 2) * 8;   // 16-byte unit tid: column tid / 32, rows 2 (tid % 32)
                 double* const dst0 = M0 + (tid >> 5) * C64_P + (tid & 31) * 2;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.B.G), 0, (m + 1) * 32768, 0x00020000);
                 union U { c64_u4 u; d2 d; };
+                U g[5][8];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    U g[5][4];
+                for (int j = 0; j < 5; ++j) {
+                    const int sj = (j <= m ? j : 0) * 32768;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[j][u].u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sj + 4096 * u, 0);   // 8 columns on
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    d2 s = d2{0.0, 0.0};
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
-                        const int sj = (j <= m ? j : 0) * 32768;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) g[j][u].u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sj + 4096 * (4 * half + u), 0);   // 8 columns on
+                        const double cj = j <= m ? ub[j] : 0.0;
+                        s.x += cj * g[j][u].d.x; s.y += cj * g[j][u].d.y;
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        d2 s = d2{0.0, 0.0};
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            const double cj = j <= m ? ub[j] : 0.0;
-                            s.x += cj * g[j][u].d.x; s.y += cj * g[j][u].d.y;
-                        }
-                        *reinterpret_cast<d2*>(dst0 + 8 * (4 * half + u) * C64_P) = s;
-                    }
+                    *reinterpret_cast<d2*>(dst0 + 8 * u * C64_P) = s;
                 }
             } else {
                 for (int i = tid; i < 64 * 32; i += 256) {       // 16-byte units
