@@ -568,7 +568,7 @@ __device__ __forceinline__ unsigned s64_row16_max_u32(unsigned v) {
 }
 
 template <int MP, int NX>
-__global__ void __launch_bounds__(256, 1) k_sweep_s64(FusedSweepArgs a) {
+__global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
     constexpr int ZS = S64Lds::ZS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
@@ -639,20 +639,17 @@ __global__ void __launch_bounds__(256, 1) k_sweep_s64(FusedSweepArgs a) {
     // ---- B role: lane (lr, lq) feeds column lr, rows 16 w + 4 ks + lq of the term panel
     const bool bok = lr < NC;
     const int bty = bok ? lr / ipw : 0, bin = bok ? lr - bty * ipw : 0;
-    double cA[MP];
-#pragma unroll
-    for (int g = 0; g < MP; ++g) cA[g] = bok && g <= m ? cg[g * ipw + bin] : 0.0;
+    // (the per-generator coefficients stay in LDS and are fetched where they are used: with 160 registers of stationary operand a
+    // second workgroup per CU -- which hides this one's barriers and reductions -- fits only if everything else stays under 96)
     const int zoff1 = lr * ZS + 16 * w + lq;
-    int zoff2[NX > 0 ? NX : 1];
-    double cBg[MP][NX > 0 ? NX : 1];
+    int zoff2[NX > 0 ? NX : 1], gx[NX > 0 ? NX : 1];
+    double cb[NX > 0 ? NX : 1];
 #pragma unroll
     for (int x = 0; x < NX; ++x) {
         const bool has = bok && x < xn[bty];
-        const int gx = has ? xg[2 * bty + x] : -1;
-        const double cb = has ? sE[bin] * xm[2 * bty + x] : 0.0;
+        gx[x] = has ? xg[2 * bty + x] : -1;
+        cb[x] = has ? sE[bin] * xm[2 * bty + x] : 0.0;
         zoff2[x] = (has ? xs[2 * bty + x] * ipw + bin : lr) * ZS + 16 * w + lq;
-#pragma unroll
-        for (int g = 0; g < MP; ++g) cBg[g][x] = g == gx ? cb : 0.0;
     }
     // ---- A role: G_g[row 16 ti + lr][k = 16 w + 4 ks + lq], column-major generators
     // (generator slots beyond m hold zeros: no branch inside the MFMA stream)
@@ -715,25 +712,38 @@ __global__ void __launch_bounds__(256, 1) k_sweep_s64(FusedSweepArgs a) {
                 d4 acc[4];
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) acc[ti] = d4{0.0, 0.0, 0.0, 0.0};
-                // all B fragments first: vector and matrix FP64 share a pipe, an FMA between two MFMAs costs a bubble
-                double bf[MP][4];
+                // the B fragments of two generators at a time, in front of their 32 MFMAs: vector and matrix FP64 share a pipe, an
+                // FMA between two MFMAs costs a bubble (per switch, not per operation)
 #pragma unroll
-                for (int g = 0; g < MP; ++g)
+                for (int g0 = 0; g0 < MP; g0 += 2) {
+                    double bf[2][4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        bf[g][ks] = cA[g] * z1[ks];
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = g0 + gg;
+                        if (g < MP) {
+                            const double cA = bok && g <= m ? cg[g * ipw + bin] : 0.0;
 #pragma unroll
-                        for (int x = 0; x < NX; ++x) bf[g][ks] = fma(cBg[g][x], z2[x][ks], bf[g][ks]);
+                            for (int ks = 0; ks < 4; ++ks) {
+                                bf[gg][ks] = cA * z1[ks];
+#pragma unroll
+                                for (int x = 0; x < NX; ++x) bf[gg][ks] = fma(gx[x] == g ? cb[x] : 0.0, z2[x][ks], bf[gg][ks]);
+                            }
+                        }
                     }
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < MP; ++g)
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = g0 + gg;
+                        if (g < MP) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
+                            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                        for (int ti = 0; ti < 4; ++ti)
-                            acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[g][ks], af[g][ks][ti], acc[ti], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                                for (int ti = 0; ti < 4; ++ti)
+                                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[gg][ks], af[g][ks][ti], acc[ti], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 d2* pw = Pb + (size_t)((t & 1) * 16 + w) * 128 + lane;   // [parity][tile][wave][half][lane]
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) {

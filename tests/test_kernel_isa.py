@@ -62,24 +62,32 @@ def isa_fused(tmp_path_factory):
 
 
 def test_s64_generators_stay_in_registers_and_the_mfma_stream_is_clean(isa_fused):
-    """80 (48) stationary generator doubles per lane loaded ONCE, before the Taylor loop; per term one uninterrupted stream of
-    16 MP MFMAs with no memory instruction, no scratch and no accumulator shuffling between register files inside it (a build
-    with a branch per generator moved all 32 accumulator registers VGPR <-> AGPR around every block of 16)."""
+    """80 (48) stationary generator doubles per lane loaded ONCE, before the Taylor loop; per term the MFMAs come in batches of 32
+    (two generators: their B fragments are formed in front of the batch) with no memory instruction and no accumulator shuffling
+    between register files inside a batch (a build with a branch per generator moved all 32 accumulator registers VGPR <-> AGPR
+    around every block of 16).  The kernel is held to 256 registers (two workgroups per CU hide each other's barriers): what the
+    five-generator instances spill are loop-invariant values, stored once before the loop."""
     names = re.findall(r"^(_ZN3dto12_GLOBAL__N_111k_sweep_s64ILi(\d)ELi(\d)EEEvNS0_14FusedSweepArgsE):", isa_fused, re.M)
     assert len(names) == 6, names                              # MP in {5, 3} x NX in {0, 1, 2}
     for nm, mp, nx in names:
         mp = int(mp)
         body = isa_fused[isa_fused.index(nm + ":"):]
         body = body[:body.index("s_endpgm")].split("\n")
-        assert not any("scratch_" in l for l in body), nm
+        meta = isa_fused[isa_fused.index(".amdhsa_kernel " + nm):]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, nm      # two waves per SIMD
         mf = [k for k, l in enumerate(body) if "v_mfma_f64_16x16x4_f64" in l]
         assert len(mf) % (16 * mp) == 0 and 1 <= len(mf) // (16 * mp) <= 2, (nm, len(mf))   # (the first term may be peeled)
         first = mf[0]
-        # the stationary loads all come before the first MFMA ...
+        # the stationary loads all come before the first MFMA, and so does every spill store ...
         assert sum(1 for l in body[:first] if re.search(r"\bglobal_load_dwordx2", l)) >= 16 * mp, nm
+        assert not any("scratch_store" in l for l in body[first:]), nm
+        if mp == 3:
+            assert not any("scratch_" in l for l in body), nm
         for s in range(0, len(mf), 16 * mp):
-            inside = body[mf[s]:mf[s + 16 * mp - 1] + 1]
-            # ... and each stream of 16 MP MFMAs holds nothing that touches memory, and no accumulator shuffling (the largest
-            # instance parks six stationary fragments in AGPRs and reads them back: 12 moves, tolerated)
-            assert not any(re.search(r"\b(global_|buffer_|ds_|v_accvgpr_write)", l) for l in inside), nm
-            assert sum(1 for l in inside if "v_accvgpr_read" in l) <= 16, nm
+            term = mf[s:s + 16 * mp]
+            for b in range(0, 16 * mp, 32):
+                batch = term[b:b + 32]
+                inside = body[batch[0]:batch[-1] + 1]
+                # ... and a batch holds nothing that touches global memory or LDS, and no accumulator shuffling
+                assert not any(re.search(r"\b(global_|buffer_|ds_|v_accvgpr_write)", l) for l in inside), nm
+                assert sum(1 for l in inside if "v_accvgpr_read" in l or "scratch_load" in l) <= 16, nm
