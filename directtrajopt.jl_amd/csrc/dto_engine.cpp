@@ -2484,7 +2484,9 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                 alloc_sweep(h, b, b.ad, 1 + m, true);
                 // pairing path: term stores for both sweeps + E_j*terms + Beta-weighted sums (skipped when they
                 // would take more than 40 % of the free HBM: the second-order sweep is then used)
-                const int dcap = 64, T1 = 1 + m;
+                // (80 terms: the step budget from the cheap norm bound of the 256 x 2000 benchmark is 66 -- with 64 the Hessian
+                // bought the exact norms, a store-less basis GEMM and two round trips, only to fit its budget into the store)
+                const int dcap = PAIR_DCAP, T1 = 1 + m;
                 const double bytes = (double)dcap * T1 * b.fw.Kpad * b.k.npad * 8.0;
                 static const bool pair_on = tune_int("DTO_HESS_PAIRING", 1) != 0;
                 size_t free_b = 0, total_b = 0;
@@ -2502,9 +2504,10 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
                     }
                     b.EP = own(h, dalloc<double>((size_t)m * dcap * b.fw.Kpad * b.k.npad));  // G_j' U_a
                     b.Upair = own(h, dalloc<double>(store));
-                    std::vector<double> bt(64 * 64);
-                    for (int a = 0; a < 64; ++a)
-                        for (int c = 0; c < 64; ++c) bt[a * 64 + c] = std::exp(std::lgamma(a + 1.0) + std::lgamma(c + 1.0) - std::lgamma(a + c + 2.0));
+                    std::vector<double> bt(PAIR_DCAP * PAIR_DCAP);
+                    for (int a = 0; a < PAIR_DCAP; ++a)
+                        for (int c = 0; c < PAIR_DCAP; ++c)
+                            bt[a * PAIR_DCAP + c] = std::exp(std::lgamma(a + 1.0) + std::lgamma(c + 1.0) - std::lgamma(a + c + 2.0));
                     b.d_Btab = own(h, dupload(bt));
                     b.pairing = true;
                 }

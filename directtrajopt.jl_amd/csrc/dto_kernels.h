@@ -60,6 +60,7 @@ constexpr double EXPM3_D[5] = {0.0035917931833685884, -0.8738586720421705, -0.10
 constexpr double EXPM3_E[5] = {-0.0814706004657684, 0.10462167443095102, 0.008296003021444887, 0.0020999533880951024, 0.00010675255813813872};
 constexpr double EXPM3_AL = 0.009959087291030108, EXPM3_BE = 3.6322128429901483;
 static_assert(EXPM3_A[4] == 0.0 && EXPM3_C[4] == 0.0 && EXPM3_D[4] == 0.0, "the second product's epilogue does not read A^4");
+constexpr int PAIR_DCAP = 80;               // Taylor terms the Hessian's pairing path can store per sweep (rows / columns of its Beta table)
 constexpr int MAX_TYPES = 36;                // column types of a generator sweep (p, d^i, h^{ij})
 constexpr int MAX_DRIVES = 7;
 

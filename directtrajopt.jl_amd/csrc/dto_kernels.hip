@@ -1671,7 +1671,7 @@ __global__ void __launch_bounds__(256) k_pair_combine(SweepBuf ad, int T, int nf
         for (int b = 0; b < na; ++b) {
             const double v = src[b * tstride];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += Btab[(a0 + q) * 64 + b] * v;
+            for (int q = 0; q < 8; ++q) acc[q] += Btab[(a0 + q) * PAIR_DCAP + b] * v;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
