@@ -77,6 +77,8 @@ struct BilHost {
     // reuse_forward_sweep: what b.fw still holds for the cached Z -- 0 nothing, 1 the p sums (S type 0), 2 p and d^j sums
     // and GY, 3 additionally every Taylor term in fw.Zt (cache_steps of them)
     int cache_kind = 0, cache_steps = 0;
+    // option reuse_forward_sweep: the step budget the Jacobian's chain planned from its exact norms at the cached point (q = 0: none)
+    int plan_q = 0, plan_dub = 0;
     // ... and whether the Taylor terms of the p column of that point sit in fw.Zt ([term][Kpad][npad], one type per term:
     // eval_constraint and the Hessian's forward sweep store them), p_steps + 1 of them, valid counts per block in fw.nterms_p
     bool p_terms = false;
@@ -1179,7 +1181,7 @@ bool same_point(dto_handle* h, const double* dZ, hipStream_t st) {
         h->d_Zcache = own(h, dalloc<double>((size_t)h->n_vars));
         h->d_eq = own(h, dalloc<int32_t>(1));
         HIP_CHECK(hipMemcpyAsync(h->d_Zcache, dZ, sizeof(double) * (size_t)h->n_vars, hipMemcpyDeviceToDevice, st));
-        for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
+        for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; b.plan_q = 0; }
         return false;
     }
     int32_t* flag = reinterpret_cast<int32_t*>(h->h_pinned + 24);
@@ -1190,7 +1192,7 @@ bool same_point(dto_handle* h, const double* dZ, hipStream_t st) {
     HIP_CHECK(hipStreamSynchronize(st));
     if (*flag) return true;
     HIP_CHECK(hipMemcpyAsync(h->d_Zcache, dZ, sizeof(double) * (size_t)h->n_vars, hipMemcpyDeviceToDevice, st));
-    for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
+    for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; b.plan_q = 0; }
     return false;
 }
 
@@ -1394,7 +1396,9 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 // ||A^t|| <= ||A^2||^floor(t/2) ||A||^(t mod 2): the exact d2 of the chain is the sharper
                 // (and still rigorous) growth rate for the sweep's step budget
                 if (swept) return;
-                sweep_with(plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2));
+                const SweepPlan from_chain = plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2);
+                if (h->reuse) { b.plan_q = from_chain.q; b.plan_dub = from_chain.d_ub; }  // a Hessian at this very point need not buy the norms again
+                sweep_with(from_chain);
             }, [&] {
                 if (lone && !keep_constants && !zeroed) {
                     // every entry but the -E_k blocks, which the chain overwrites
@@ -1464,7 +1468,10 @@ void do_hessian(dto_handle* h, const double* dZ, double sigma, const double* dmu
             }
             // (the budget from the cheap bound serves while the term store holds it: the sweeps end by their own test, and the
             // pairing loops run over the terms actually produced -- the exact norms cost a store-less basis GEMM and two round trips)
-            SweepPlan plan = plan_from(h, b, dZ, st, /*loose=*/b.pairing);
+            // (reuse_forward_sweep, same point as the last Jacobian: the chain's exact norms have planned that call's sweep already --
+            // at 1024 states the passes that establish q = 1 for a Hessian on its own are 4.9 of its 29.5 ms)
+            const bool planned = same && b.plan_q > 0;
+            SweepPlan plan = planned ? SweepPlan{b.plan_q, b.plan_dub} : plan_from(h, b, dZ, st, /*loose=*/b.pairing);
             if (plan.tc >= 0 && plan.d_ub + 1 > b.fw.dcap) plan = plan_from(h, b, dZ, st);
             const bool pair = b.pairing && plan.q == 1 && plan.d_ub + 1 <= b.fw.dcap;
             const int m = b.k.m, T1 = 1 + m;
@@ -1786,7 +1793,7 @@ double* staging(dto_handle* h, size_t n) {
 }
 
 void drop_caches(dto_handle* h) {
-    for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; }
+    for (auto& b : h->bil) { b.cache_kind = 0; b.p_terms = false; b.plan_q = 0; }
 }
 void unprime(dto_handle* h) { h->primed[0] = h->primed[1] = false; }
 
