@@ -483,3 +483,33 @@ def test_host_pointer_calls_back_to_back_match_the_device_resident_ones():
             torch.cuda.synchronize()
             assert rel_err(h, hd.cpu().numpy()) <= 1e-12, it
     ev.close()
+
+
+def test_reuse_takes_the_chains_step_budget_where_the_cheap_bound_is_not_enough():
+    """Large time steps on the batched-GEMM path (96 states): the cheap norm bound asks for sub-steps, so a Hessian on its own buys the
+    exact norms of A^2..A^4 for its step budget; with reuse_forward_sweep a Hessian that follows the Jacobian at the same point takes
+    the budget that call's chain planned.  Same numbers either way (to rounding), against the oracle, the point changing in between."""
+    import dto_amd
+    p = O.make_scaled_problem(5, 96, 2, seed=96, skew=True)
+    Z1 = p.Z0.copy()
+    Z1[p.dt_idx::p.z] = 0.1 * np.sqrt(256.0 / 96) * 4.0 * np.array([2.0, 0.7, 3.0, 1.3, 1.0])
+    Z2 = Z1.copy()
+    Z2[p.dt_idx::p.z] *= 0.8
+    ev_o = O.OracleEvaluator(p)
+    ref = dto_amd.Evaluator(to_engine(p))
+    ev = dto_amd.Evaluator(to_engine(p))
+    ev.set_option("reuse_forward_sweep", 1)
+    mu = np.random.default_rng(3).standard_normal(ev_o.n_constraints)
+    try:
+        for Z in (Z1, Z2, Z1):
+            J = np.empty(ev.n_jacobian_entries); ev.eval_constraint_jacobian(J, Z)
+            H = np.empty(ev.n_hessian_entries); ev.eval_hessian_lagrangian(H, Z, 0.9, mu)
+            J0 = np.empty(ref.n_jacobian_entries); ref.eval_constraint_jacobian(J0, Z)
+            H0 = np.empty(ref.n_hessian_entries); ref.eval_hessian_lagrangian(H0, Z, 0.9, mu)
+            assert rel_err(J, J0) <= 1e-12 and rel_err(H, H0) <= 1e-11
+            assert rel_err(J, ev_o.eval_constraint_jacobian(Z)) <= 1e-9
+            assert rel_err(H, ev_o.eval_hessian_lagrangian(Z, 0.9, mu)) <= 1e-7
+            H2 = np.empty(ev.n_hessian_entries); ev.eval_hessian_lagrangian(H2, Z, 0.9, mu)   # again, the budget still cached
+            assert rel_err(H2, H0) <= 1e-11
+    finally:
+        ref.close(); ev.close()
