@@ -226,6 +226,7 @@ struct dto_handle {
     double* d_partial = nullptr;
     double* d_f = nullptr;
     double* d_bounds = nullptr;  // [2] max beta, max b1 (as uint64 bit patterns)
+    int32_t* d_plan = nullptr;   // [4] {q, d_ub, tc} of a sweep planned on the device from d_bounds (launch_plan_dev)
     double* d_jac_scratch = nullptr;     // value slab for the Jacobian-vector products (lazy)
     double* d_w = nullptr;               // product input
     int64_t* d_conbase = nullptr;        // [n_vars+1] first constraint-pattern entry of each column
@@ -598,6 +599,14 @@ bool gs_sweep_applies(const dto_handle* h, const BilHost& b, const SweepBuf& w, 
                       bool shared_chip, GsSweepPlan& gp);
 bool ensure_bind_runs(dto_handle* h, int which);
 
+// Does this sweep run in the 64-state generator-stationary form, which can read its step budget from device memory?  (No term
+// store, no reuse: the host then needs nothing of the plan.)
+bool s64_plans_itself(const dto_handle* h, const BilHost& b, const SweepBuf& w, const SweepTypes& ty) {
+    static const int on = tune_int("DTO_PLAN_DEV", 1);  // A/B runs (TUNING builds)
+    FusedSweepPlan fp;
+    return on && !h->reuse && h->sweep_form != 1 && !w.frozen && b.k.npad == 64 && sweep_fused_plan(w.npad, b.k.m, ty, h->P.n_int, h->n_cu, fp) && fp.S64;
+}
+
 // 33..64 states: the propagator chain as one launch (dto_chain64.hip)
 bool chain64_applies(const dto_handle* h, const BilHost& b) {
     static const int chain64_on = tune_int("DTO_CHAIN64", 1);  // A/B runs (TUNING builds)
@@ -608,7 +617,8 @@ bool chain64_applies(const dto_handle* h, const BilHost& b) {
 // (term t of all types at Zt + t*T*Kpad*npad) instead of ping-ponging two buffers.
 int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, const double* dZ, const double* dmu,
               int src_kind, int transposed, const SweepPlan& plan, hipStream_t st, bool store = false,
-              bool skip_init = false, bool want_steps = false, bool shared_chip = false, int prof_cat = CAT_SWEEP) {
+              bool skip_init = false, bool want_steps = false, bool shared_chip = false, int prof_cat = CAT_SWEEP,
+              const int32_t* plan_dev = nullptr) {
     const double flops_step = [&] {
         double segs = 0;
         for (int t = w.frozen ? w.first_type : 0; t < ty.T; ++t) segs += b.k.m + 1;  // an extra term rides in the segment of its generator
@@ -652,11 +662,13 @@ int run_sweep(dto_handle* h, BilHost& b, SweepBuf& w, const SweepTypes& ty, cons
         {
             // flops of the step budget (an upper bound: workgroups leave when their columns have converged)
             ProfScope ps(h, st, prof_cat, flops_step * plan.d_ub * plan.q);
-            HIP_CHECK(launch_sweep_fused(st, h->P, b.k, w, ty, fp, dZ, dmu, src_kind, transposed, plan.q, plan.d_ub, tc, store, 1.1e-16));
+            HIP_CHECK(launch_sweep_fused(st, h->P, b.k, w, ty, fp, dZ, dmu, src_kind, transposed, plan.q, plan.d_ub, tc, store, 1.1e-16,
+                                         plan_dev));
         }
         if (!want_steps) return plan.d_ub;
         return fused_sweep_steps(h, w, plan.d_ub, st);
     }
+    if (plan_dev) throw HipError{"run_sweep: a device-side plan without the form that reads it"};
     // Row-split cluster form: where the single-workgroup form has too few interval groups for the chip -- short shards of 128-
     // and 256-state problems (the 250-knot share of the 2000-knot metric on 8 GPUs).  Measured per Jacobian / Hessian,
     // cluster against step per launch (tools/cluster_time.py): 256 x 250 2.12 / 2.02 against 2.22 / 2.04 ms, 128 x 250 0.74 /
@@ -1268,7 +1280,15 @@ void do_constraint(dto_handle* h, const double* dZ, double* dg, hipStream_t st) 
             continue;
         }
         if (h->P.n_int > 0) {
-            if (!(same && b.cache_kind >= 1)) {  // else exp(A)x of this very point is still in b.fw.S
+            if (!(same && b.cache_kind >= 1) && s64_plans_itself(h, b, b.fw, make_types(0, false))) {
+                // 33..64 states: the one-launch sweep takes its step budget from the norm bound ON THE DEVICE (k_plan_dev: the
+                // formulas of cheap_plan / plan_sweep) -- the call no longer waits 40 us for eight bytes
+                enqueue_bounds(h, b, dZ, st);
+                launch_plan_dev(st, reinterpret_cast<const unsigned long long*>(h->d_bounds), h->d_plan);
+                run_sweep(h, b, b.fw, make_types(0, false), dZ, nullptr, 0, 0, SweepPlan{1, 200}, st, false, false, false, false, CAT_SWEEP, h->d_plan);
+                b.cache_kind = 0;
+                remember_p_terms(h, b, false, 0, st);
+            } else if (!(same && b.cache_kind >= 1)) {  // else exp(A)x of this very point is still in b.fw.S
                 SweepPlan plan = plan_from(h, b, dZ, st, /*loose=*/true);
                 if (plan.tc >= 0 && h->reuse && b.pairing && plan.d_ub + 1 > b.fw.dcap) plan = plan_from(h, b, dZ, st);  // the term store is what limits
                 SweepTypes ty = make_types(0, false);
@@ -1329,7 +1349,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 HIP_CHECK(hipEventRecord(h->ev_fork, st));  // dZ (and the zero-filled slab) are ready here
                 HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
             }
-            auto sweep_with = [&](SweepPlan plan) {
+            auto sweep_with = [&](SweepPlan plan, const int32_t* plan_dev = nullptr) {
                 SweepTypes ty = make_types(b.k.m, false);
                 // the p column of this very point is stored (eval_constraint or a Hessian came first)
                 const bool have_p = same && b.p_terms && plan.q == 1;
@@ -1362,7 +1382,7 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
                 const bool gs_alone = gs_sweep_applies(h, b, b.fw, ty, plan, keep, false, gp_j);
                 hipStream_t sw = gs_alone ? st : ss;
                 const int steps = run_sweep(h, b, b.fw, ty, dZ, nullptr, 0, 0, plan, sw, keep, false, false,
-                                            /*shared_chip=*/overlap && !h->deterministic && !gs_alone);
+                                            /*shared_chip=*/overlap && !h->deterministic && !gs_alone, CAT_SWEEP, plan_dev);
                 launch_apply_Gu(sw, b.k, b.fw, 0, b.fw.S, b.fw.GY);
                 b.cache_kind = h->reuse ? (keep ? 3 : 2) : 0;
                 b.cache_steps = steps;
@@ -1375,19 +1395,34 @@ void do_jacobian(dto_handle* h, const double* dZ, double* dvals, hipStream_t st)
             bool swept = same && b.cache_kind >= 2;  // the tangent sums of this very point are still in b.fw
             bool zeroed = false;
             static const int early_on = tune_int("DTO_SWEEP_EARLY", 1);  // A/B runs (TUNING builds)
+            if (!swept && early_on && chain64_applies(h, b) && s64_plans_itself(h, b, b.fw, make_types(b.k.m, false))) {
+                // ... and planned on the device: the whole call is enqueue-only
+                launch_plan_dev(st, reinterpret_cast<const unsigned long long*>(h->d_bounds), h->d_plan);
+                HIP_CHECK(hipEventRecord(h->ev_fork, st));   // the plan is ready here
+                if (overlap) HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
+                sweep_with(SweepPlan{1, 200}, h->d_plan);
+                swept = true;
+                if (lone && !keep_constants) {
+                    // the fill behind the sweep on ITS stream: only the tangent-column writers after the join need it, and the chain
+                    // (which skips nothing the fill touches) starts 28 us earlier than with the fill in front of it
+                    ProfScope ps(h, ss, CAT_ZERO, 8.0 * ((double)h->info.jac_len - (double)h->P.n_int * b.k.n * b.k.n));
+                    launch_jac_zero(ss, h->P, b.k, dvals);
+                    zeroed = true;
+                }
+            }
             if (!swept && early_on && chain64_applies(h, b)) {   // (with or without overlap: the plan, hence the bits, must not depend on it)
                 HIP_CHECK(hipStreamSynchronize(st));
                 bd = Bounds{h->h_pinned[0], h->h_pinned[1]};
                 SweepPlan early;
                 if (cheap_plan(bd, /*loose=*/true, early)) {
-                    if (lone && !keep_constants) {
-                        // (the fill no longer has a host wait to hide in: it goes first, beside the sweep)
-                        ProfScope ps(h, st, CAT_ZERO, 8.0 * ((double)h->info.jac_len - (double)h->P.n_int * b.k.n * b.k.n));
-                        launch_jac_zero(st, h->P, b.k, dvals);
-                        zeroed = true;
-                    }
                     sweep_with(early);
                     swept = true;
+                    if (lone && !keep_constants) {
+                        // (the fill no longer has a host wait to hide in: it goes behind the sweep, on the sweep's stream)
+                        ProfScope ps(h, ss, CAT_ZERO, 8.0 * ((double)h->info.jac_len - (double)h->P.n_int * b.k.n * b.k.n));
+                        launch_jac_zero(ss, h->P, b.k, dvals);
+                        zeroed = true;
+                    }
                 }
             }
             const bool nothing_waits = swept && chain64_applies(h, b);
@@ -2463,6 +2498,7 @@ int dto_create(const dto_problem_desc* d, dto_handle** out) {
         h->d_partial = own(h, dalloc<double>(256));
         h->d_f = own(h, dalloc<double>(1));
         h->d_bounds = own(h, dalloc<double>(2));
+        h->d_plan = own(h, dalloc<int32_t>(4));
         HIP_CHECK(hipHostMalloc((void**)&h->h_pinned, 32 * sizeof(double)));
         HIP_CHECK(hipHostMalloc((void**)&h->h_stats, sizeof(int32_t) * 4 * std::max<size_t>(h->bil.size(), 1)));
         memset(h->h_stats, 0, sizeof(int32_t) * 4 * std::max<size_t>(h->bil.size(), 1));

@@ -253,7 +253,9 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
 // w.stats[0] += workgroups that did not converge, w.stats[1] = max terms used (the caller zeroes w.stats).
 hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
                               const FusedSweepPlan& pl, const double* dZ, const double* dmu, int src_kind, int transposed,
-                              int q, int d_ub, int tc, bool store, double tol);
+                              int q, int d_ub, int tc, bool store, double tol, const int32_t* plan_dev = nullptr);
+// {q, d_ub, tc} of a sweep from the norm bound (bit pattern in bounds[0]), computed on the device: launch_sweep_fused(..., plan_dev)
+void launch_plan_dev(hipStream_t st, const unsigned long long* bounds, int32_t* out);
 
 // ---- the same sweep with the rows of the matrix split over a cluster of R workgroups that exchange their slices of every new
 // term through global memory (dto_sweep_fused.hip): short shards, single-column sweeps, 512+ states

@@ -46,6 +46,8 @@ struct FusedSweepArgs {
     const double* mu;    // multipliers (src_kind 1)
     int src_kind, q, d_ub, tc, ipw, store, nslot;
     double tol;
+    const int32_t* plan_dev;   // k_sweep_s64 only, nullable: {q, d_ub, tc} planned ON THE DEVICE from the norm bound (k_plan_dev) -- the
+                               // host then never waits for the bound
 };
 
 constexpr int PF = 4;  // k-steps (of 4) the A fragments are loaded ahead
@@ -575,6 +577,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
     const int Kpad = a.w.Kpad, T = a.ty.T, m = a.B.m, ipw = a.ipw, NC = T * ipw;
     const int64_t typesz = (int64_t)Kpad * 64;
     const int k0 = blockIdx.x * ipw;
+    const int plan_q = a.plan_dev ? a.plan_dev[0] : a.q, plan_dub = a.plan_dev ? a.plan_dev[1] : a.d_ub, plan_tc = a.plan_dev ? a.plan_dev[2] : a.tc;
     const S64Lds L(T, m, ipw);
     double* Zs = lds + L.zs;
     d2* Pb = reinterpret_cast<d2*>(lds + L.pb);
@@ -593,7 +596,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
         const bool live = kl < a.P.n_int;
         const double* zk = a.Zsrc + (a.P.kn_lo + kl) * a.P.z;
         const double dt = live ? zk[a.P.dt_idx] : 0.0;
-        const double inv_q = 1.0 / a.q;
+        const double inv_q = 1.0 / plan_q;
         sE[tid] = dt * inv_q;
         if (kl < Kpad) {
             a.w.scaleE[kl] = dt * inv_q;
@@ -680,7 +683,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
 
     int t_exit = 0;
     bool conv = false;
-    for (int round = 0; round < a.q; ++round) {
+    for (int round = 0; round < plan_q; ++round) {
         if (round > 0) {
             // next sub-interval of exp(A) = exp(A/q)^q: the sums become term 0 of the new series
 #pragma unroll
@@ -700,7 +703,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
         conv = false;
         int t = 0;
         for (;; ++t) {
-            if (t < a.d_ub) {
+            if (t < plan_dub) {
                 // ---- partial products of term t+1 over this wavefront's k range
                 double z1[4], z2[NX > 0 ? NX : 1][4];
 #pragma unroll
@@ -753,7 +756,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
             }
             __syncthreads();
             // ---- Al-Mohy & Higham's test of the pair (t-1, t), whose norms every wavefront has delivered before this barrier
-            if (t >= 1 && t - 1 >= a.tc) {
+            if (t >= 1 && t - 1 >= plan_tc) {
                 bool more = false;
                 if (lane < NC) {
                     const double a0 = fbits_to_d(tn[((t - 1) & 3) * 16 + lane]), a1 = fbits_to_d(tn[(t & 3) * 16 + lane]);
@@ -762,7 +765,7 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
                 }
                 if (__ballot(more) == 0ull) { conv = true; break; }
             }
-            if (t == a.d_ub) break;
+            if (t == plan_dub) break;
             // ---- term t+1 of row tile w: the four partials in wavefront order
             const double inv = 1.0 / (double)(t + 1);
             d4 v;
@@ -798,8 +801,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep_s64(FusedSweepArgs a) {
             }
             if (w == 0 && lane < 16) { tn[((t + 2) & 3) * 16 + lane] = 0ull; sn[((t + 2) & 3) * 16 + lane] = 0ull; }
         }
-        t_exit = conv ? t + 1 : a.d_ub + 1;  // terms 0 .. t_exit - 1 exist
-        if (round + 1 < a.q) __syncthreads();
+        t_exit = conv ? t + 1 : plan_dub + 1;  // terms 0 .. t_exit - 1 exist
+        if (round + 1 < plan_q) __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1517,10 +1520,50 @@ hipError_t launch_sweep_cluster(hipStream_t st, const KProb& P, const KBil& B, c
     return hipErrorInvalidValue;
 }
 
+// The step budget of a sweep from the cheap norm bound alone, on the device (one lane): the host's cheap_plan(loose) where it gives a
+// single round, else its plan_sweep -- same formulas, same constants (dto_engine.cpp), so the numbers are those a host that waited
+// for the bound would have used.  out = {q, d_ub, tc}.
+__global__ void k_plan_dev(const unsigned long long* __restrict__ bounds, int32_t* __restrict__ out) {
+    const double beta = __longlong_as_double((long long)bounds[0]);
+    auto budget = [](double br) {
+        int t = 8;
+        double term = 1.0;
+        for (int i = 1; i <= t; ++i) term *= br / i;
+        while (term > 1e-19 && t < 200) { ++t; term *= br / t; }
+        return t + 6;
+    };
+    int q = 1, d_ub = 30, tc = -1;
+    if (beta == beta && beta <= 1e6) {
+        q = (int)ceil(beta / 9.0);
+        if (q < 1) q = 1;
+        d_ub = budget(beta / q);
+        if (q > 1 && beta < 40.0) {
+            // the hump criterion on the bound itself: max_k beta^k / k! <= e^9 (the maximum sits at k = floor(beta) or next to it)
+            double lh = 0.0;
+            const int k0 = (int)floor(beta);
+            for (int k = (k0 > 1 ? k0 - 1 : 1); k <= k0 + 1; ++k) lh = fmax(lh, k * log(beta) - lgamma(k + 1.0));
+            if (lh <= 9.0) {
+                q = 1;
+                d_ub = budget(beta);
+                const int a0 = d_ub / 2 - 1, a1 = (int)ceil(beta) + 4;
+                tc = a0 < (a1 > 2 ? a1 : 2) ? a0 : (a1 > 2 ? a1 : 2);
+            }
+        }
+    }
+    if (tc < 0) tc = d_ub / 2 - 1;
+    if (tc < 2) tc = 0;
+    out[0] = q; out[1] = d_ub; out[2] = tc;
+}
+void launch_plan_dev(hipStream_t st, const unsigned long long* bounds, int32_t* out) {
+    hipLaunchKernelGGL(k_plan_dev, dim3(1), dim3(1), 0, st, bounds, out);
+}
+
 hipError_t launch_sweep_fused(hipStream_t st, const KProb& P, const KBil& B, const SweepBuf& w, const SweepTypes& ty,
                               const FusedSweepPlan& pl, const double* dZ, const double* dmu, int src_kind, int transposed,
-                              int q, int d_ub, int tc, bool store, double tol) {
+                              int q, int d_ub, int tc, bool store, double tol, const int32_t* plan_dev) {
+    if (plan_dev && !pl.S64) return hipErrorInvalidValue;   // only the 64-state form reads its plan from the device
     FusedSweepArgs a{};
+    a.plan_dev = plan_dev;
     a.P = P; a.B = B; a.w = w; a.ty = ty;
     a.G = transposed ? B.GT : B.G;
     a.Zsrc = dZ; a.mu = dmu; a.src_kind = src_kind;
