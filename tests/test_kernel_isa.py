@@ -72,7 +72,7 @@ def test_s64_generators_stay_in_registers_and_the_mfma_stream_is_clean(isa_fused
     for nm, mp, nx in names:
         mp = int(mp)
         body = isa_fused[isa_fused.index(nm + ":"):]
-        body = body[:body.index("s_endpgm")].split("\n")
+        body = body[:body.index(".Lfunc_end")].split("\n")    # (the kernel may hold more than one s_endpgm)
         meta = isa_fused[isa_fused.index(".amdhsa_kernel " + nm):]
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, nm      # two waves per SIMD
         mf = [k for k, l in enumerate(body) if "v_mfma_f64_16x16x4_f64" in l]
