@@ -707,8 +707,9 @@ def main():
                        "inputs": "Z and the value slab resident in HBM; the 4.2 MB host-to-device copy of Z that SURVEY.md §8d's "
                                  "metric lists is NOT in `value` (host-pointer figures: DESIGN.md §5)"},
             "roofline": {
-                "bound": "mfma", "kernel": {"hessian": "k_sweep_fused / k_sweep_gs (adjoint generator sweep of the Hessian: exp(A')mu and its u-tangents, one persistent launch)",
-                                            "constraint": "k_sweep_gs / k_sweep (generator sweep of the p column: exp(A)x)"}.get(
+                "bound": "mfma", "kernel": {"hessian": ("k_sweep_s64" if n <= 64 else "k_sweep_fused / k_sweep_gs") +
+                                                       " (adjoint generator sweep of the Hessian: exp(A')mu and its u-tangents, one persistent launch)",
+                                            "constraint": ("k_sweep_s64" if 32 < n <= 64 else "k_sweep_gs / k_sweep") + " (generator sweep of the p column: exp(A)x)"}.get(
                                                 args.callback, "k_chain64 (the propagator chain of a 33..64-state integrator in ONE launch, a workgroup per interval: "
                                                                "powers, polynomial products and squarings on FP64 MFMA out of LDS; priced at six 64^3 products per interval)"
                                                 if "chain64" in variants else "k_bgemm (batched FP64 MFMA GEMM of the propagator chain)"),
