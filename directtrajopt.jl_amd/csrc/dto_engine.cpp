@@ -1175,9 +1175,13 @@ SweepPlan plan_from(dto_handle* h, BilHost& b, const double* dZ, hipStream_t st,
     Bounds bd = get_bounds(h, b, dZ, st);
     SweepPlan cheap;
     if (cheap_plan(bd, loose, cheap)) return cheap;
-    double d2 = exact_d2(h, b, dZ, st);
+    // A cheap bound far beyond one round's radius (2.5 theta_v: a function of Z alone): ||A^2|| by itself will not settle q = 1 either,
+    // so the pass over A^2 alone is skipped and the norms of A^2, A^3, A^4 are taken at once (1024 x 500, beta = 28.8: the A^2-only
+    // pass was 1.4 of the 6.4 ms the exact norms cost a Hessian or an eval_constraint there)
+    const bool straight = b.use_basis && bd.beta == bd.beta && bd.beta > 22.5;
+    double d2 = exact_d2(h, b, dZ, st, straight);
     auto plan = [&] { return plan_hump(b, d2 == d2 ? std::min(bd.beta, d2) : d2); };
-    if (d2 == d2 && plan().q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);  // ||A^3||, ||A^4|| sharpen the bound
+    if (!straight && d2 == d2 && plan().q > 1 && b.use_basis) d2 = exact_d2(h, b, dZ, st, true);  // ||A^3||, ||A^4|| sharpen the bound
     return plan();
 }
 
