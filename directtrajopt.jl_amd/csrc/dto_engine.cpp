@@ -852,7 +852,7 @@ void alloc_chain(dto_handle* h, BilHost& b, int cap) {
 
 int chunk_size(const dto_handle* h, int npad) {
     // workspace budget for the 9 chain matrices (option "chain_chunk" lowers the chunk per call)
-    const double budget = 36e9;
+    const double budget = 40e9;   // (1024 states x 500 knots, the configs[4] share, in ONE chunk: 37.7 GB)
     int c = (int)(budget / (9.0 * npad * (double)npad * 8.0));
     c = std::max(8, (c / 8) * 8);
     return (int)std::min<int64_t>(c, std::max<int64_t>(h->P.n_int, 1));
