@@ -1357,7 +1357,8 @@ bool sweep_fused_plan(int npad, int m, const SweepTypes& ty, int64_t n_int, int 
         for (int t = 0; t < T; ++t) nx = nx > ty.t[t].n_extra ? nx : ty.t[t].n_extra;
         // a workgroup's Taylor step costs the same for 1 or 16 live columns, so few intervals are spread over the CUs first
         // (one round of workgroups) and only then packed into the tile
-        int ipw = (int)((n_int + n_cu - 1) / n_cu);
+        // (beside another kernel -- the Hessian's forward column next to its adjoint sweep -- the CU time is what counts: full tiles)
+        int ipw = shared_chip ? 16 / T : (int)((n_int + n_cu - 1) / n_cu);
         ipw = ipw < 1 ? 1 : (ipw > 16 / T ? 16 / T : ipw);
         const long nblocks = (long)((n_int + ipw - 1) / ipw);
         if (nx <= 2) {
