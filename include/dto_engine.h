@@ -331,7 +331,9 @@ int dto_bind_output_dev(dto_handle* h, int32_t vector, double* dptr);
  *   other.  With this on, the engine remembers the forward generator sweep of the last callback and re-uses it when
  *   the next callback's Z is bit-identical (compared on the device, one 4-byte readback): eval_constraint after
  *   eval_jacobian then costs a copy, eval_jacobian after eval_constraint sweeps its tangent columns only, eval_hessian
- *   skips its forward sweep.  Results agree to rounding either way (the constraint-only
+ *   skips its forward sweep and -- after an eval_jacobian at that point -- takes the step budget that call's propagator chain
+ *   planned from its exact norms instead of buying them again (a sixth of a Hessian at 1024 states).  Results agree to rounding
+ *   either way (the constraint-only
  *   sweep sums its generator products in a different order than the Jacobian's); the benchmark never turns it on (each
  *   callback is timed cold). */
 /*   "expm_form" (default 0): evaluation form of the matrix-exponential polynomial in eval_constraint_jacobian.  0 picks per
