@@ -345,15 +345,20 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
                 if constexpr (WK == 2) {
                     // ---- K split: hand the other wave of the SIMD the partial sums of ITS row pair, finish the own pair
                     __syncthreads();  // every wave is done with the old term columns
+                    // (the lane coordinates are made opaque once per term: otherwise the per-element column indices, interval numbers and
+                    // store offsets of this epilogue -- 12 elements, a division each -- are computed ONCE before the term loop and kept
+                    // alive across it in scratch: ~60 scratch loads per term and wave; recomputing them is integer arithmetic)
+                    int lq_e = lq, lr_e = lr;
+                    if constexpr (MT == 4) asm volatile("" : "+v"(lq_e), "+v"(lr_e));   // (below 256 states nothing spills and the divisions would be the loss)
                     auto finish = [&](auto own_c) {
                         constexpr int OWN = decltype(own_c)::value, OTHER = 1 - OWN;
 #pragma unroll
                         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                                const int c = 16 * (ct0 + tj) + 4 * r + lq_e;
                                 if (c < NC)
-                                    *reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * OTHER + 2 * lr) =
+                                    *reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * OTHER + 2 * lr_e) =
                                         d2{acc[2 * OTHER][tj][r], acc[2 * OTHER + 1][tj][r]};
                             }
                         __syncthreads();
@@ -361,21 +366,21 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
                         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                                const int c = 16 * (ct0 + tj) + 4 * r + lq_e;
                                 const int cc = c < NC ? c : 0;
                                 const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
                                 const bool ok = c < NC && kl < Kpad;
                                 double tmax = 0.0, smax = 0.0;
                                 bool bad_t = false, bad_s = false;
                                 if (c < NC) {
-                                    d2* zpos = reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * OWN + 2 * lr);
+                                    d2* zpos = reinterpret_cast<d2*>(Zs + c * ZS + rowbase + 32 * OWN + 2 * lr_e);
                                     const d2 part = *zpos;   // the other wave's k-steps
                                     const d2 v = d2{(acc[2 * OWN][tj][r] + part.x) * inv, (acc[2 * OWN + 1][tj][r] + part.y) * inv};
                                     *zpos = v;               // the new term becomes the B operand of the next step
                                     if (ok) {
                                         const d2 sv = d2{sreg[0][tj][r] + v.x, sreg[1][tj][r] + v.y};
                                         sreg[0][tj][r] = sv.x; sreg[1][tj][r] = sv.y;
-                                        if (a.store) *reinterpret_cast<d2*>(Zout + ((int64_t)ty * Kpad + kl) * npad + rowbase + 32 * OWN + 2 * lr) = v;
+                                        if (a.store) *reinterpret_cast<d2*>(Zout + ((int64_t)ty * Kpad + kl) * npad + rowbase + 32 * OWN + 2 * lr_e) = v;
                                         tmax = fmax(fabs(v.x), fabs(v.y));
                                         smax = fmax(fabs(sv.x), fabs(sv.y));
                                         bad_t = !(v.x == v.x) || !(v.y == v.y);      // NaN must survive the max
@@ -389,7 +394,7 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
                                     tb = t2 > tb ? t2 : tb;
                                     sb = s2 > sb ? s2 : sb;
                                 }
-                                if (ok && lr == 0) {
+                                if (ok && lr_e == 0) {
                                     atomicMax(&tn_new[c], tb);
                                     atomicMax(&sn[c], sb);
                                 }
@@ -398,13 +403,15 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
                     if (wk == 0) finish(std::integral_constant<int, 0>{});
                     else finish(std::integral_constant<int, 1>{});
                 } else {
+                    int lq_e = lq, lr_e = lr;   // (opaque once per term, as in the K-split epilogue above)
+                    if constexpr (MT == 4) asm volatile("" : "+v"(lq_e), "+v"(lr_e));
                     // ---- new term of this row pass: sums, column norms, stores.  Accumulator register r of column tile tj
-                    // holds column 16 tj + 4 r + lq
+                    // holds column 16 tj + 4 r + lq_e
     #pragma unroll
                     for (int tj = 0; tj < NT; ++tj)
     #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int c = 16 * (ct0 + tj) + 4 * r + lq;
+                            const int c = 16 * (ct0 + tj) + 4 * r + lq_e;
                             const int cc = c < NC ? c : 0;
                             const int ty = cc / ipw, kl = k0 + cc - ty * ipw;
                             const bool ok = c < NC && kl < Kpad;
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
                             if (ok) {
     #pragma unroll
                                 for (int p = 0; p < (MT >= 2 ? MT / 2 : 1); ++p) {
-                                    const int64_t off = colbase + (MT >= 2 ? 32 * p + 2 * lr : lr);
+                                    const int64_t off = colbase + (MT >= 2 ? 32 * p + 2 * lr_e : lr_e);
                                     d2 v, sv;
                                     if constexpr (MT >= 2) v = d2{acc[2 * p][tj][r] * inv, acc[2 * p + 1][tj][r] * inv};
                                     else v = d2{acc[0][tj][r] * inv, 0.0};
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(256 * WC * WK, WC * WK) k_sweep_fused(FusedSwe
                                 tb = t2 > tb ? t2 : tb;
                                 sb = s2 > sb ? s2 : sb;
                             }
-                            if (ok && lr == 0) {
+                            if (ok && lr_e == 0) {
                                 atomicMax(&tn_new[c], tb);
                                 atomicMax(&sn[c], sb);
                             }
